@@ -1,0 +1,445 @@
+/*
+ * stm_oracle.c -- CPU restatement of the reference's CPU code path for the
+ * stereo cost-volume hot path (SSD / Birchfield cost fill, semiglobal
+ * aggregation, winner-takes-all and dynamic-programming reduction).
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the smoke()
+ * entry in __graft_entry__.py and the cpu_baseline leg of bench.py may load
+ * it, and only as the checker / the timed CPU baseline.  The shipped path is
+ * the HIP library (stereo-matching_amd/csrc); it never calls into this file.
+ *
+ * Pinning: the reference's own C++ cannot be compiled in this image without
+ * writing stand-in CUDA headers (include/stereomatch/cuda_utils.hpp:7 needs
+ * <cuda_runtime.h>, include/stereomatch/numeric.hpp:3 needs
+ * <math_constants.h>), so there is no oracle/_ref.  The restatement is pinned
+ * against the reference-output digests recorded in SURVEY.md Appendix C
+ * (sha256 of outputs of the reference CPU path on a seeded generator); see
+ * tests/test_oracle_pinned.py.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * the upstream repository root).  All arithmetic is IEEE binary32 with one
+ * rounding per operation; build with -ffp-contract=off and without
+ * -ffast-math (oracle/Makefile does).  Single-threaded, like the reference
+ * as shipped (its OpenMP pragmas are inert: setup.py:80 passes no -fopenmp).
+ *
+ * Volumes are [H][W][D] row-major (D innermost), images [H][W].
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_OK 0
+#define ORC_EINVAL 1
+#define ORC_ENOMEM 2
+
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+
+/* ------------------------------------------------------------------------
+ * SSD cost volume.  src/ssd.cu:31-61 (SSDKernel::operator(), CPU functor run
+ * by KernelLauncher<kCPU>::Launch2D, include/stereomatch/kernel.hpp:100-119).
+ *   window rows  [max(r-k,0), min(r+k,H))
+ *   window cols  [|min(c-d-k,0)| + c - k, min(c+k,W))  ( = max(c-k,d) )
+ *   row-major accumulation, separate multiply and add, +inf for d > c.
+ * ---------------------------------------------------------------------- */
+int orc_ssd_f32(const float *L, const float *R, float *C, int H, int W, int D,
+                int k) {
+  if (!L || !R || !C || H <= 0 || W <= 0 || D <= 0 || k < 0) return ORC_EINVAL;
+  for (int row = 0; row < H; ++row) {
+    for (int col = 0; col < W; ++col) {
+      float *out = C + ((size_t)row * W + col) * D;
+      const int dmax = imin(col + 1, D);
+      for (int disp = 0; disp < dmax; ++disp) {
+        const int row_start = imax(row - k, 0);
+        const int row_end = imin(row + k, H);
+        const int col_start = abs(imin(col - disp - k, 0)) + col - k;
+        const int col_end = imin(col + k, W);
+        float cost = 0.0f;
+        for (int kr = row_start; kr < row_end; ++kr) {
+          const float *lrow = L + (size_t)kr * W;
+          const float *rrow = R + (size_t)kr * W;
+          for (int kc = col_start; kc < col_end; ++kc) {
+            const float diff = lrow[kc] - rrow[kc - disp];
+            const float sq = diff * diff;
+            cost = cost + sq;
+          }
+        }
+        out[disp] = cost;
+      }
+      for (int disp = col + 1; disp < D; ++disp) out[disp] = INFINITY;
+    }
+  }
+  return ORC_OK;
+}
+
+/* One SSD entry, same arithmetic; used by full-size sampled parity checks. */
+float orc_ssd_entry_f32(const float *L, const float *R, int H, int W, int k,
+                        int row, int col, int disp) {
+  if (disp > col) return INFINITY;
+  const int row_start = imax(row - k, 0);
+  const int row_end = imin(row + k, H);
+  const int col_start = abs(imin(col - disp - k, 0)) + col - k;
+  const int col_end = imin(col + k, W);
+  float cost = 0.0f;
+  for (int kr = row_start; kr < row_end; ++kr) {
+    for (int kc = col_start; kc < col_end; ++kc) {
+      const float diff = L[(size_t)kr * W + kc] - R[(size_t)kr * W + kc - disp];
+      const float sq = diff * diff;
+      cost = cost + sq;
+    }
+  }
+  return cost;
+}
+
+/* ------------------------------------------------------------------------
+ * Birchfield-Tomasi cost.  src/birchfield_cost.cu:26-67
+ * (BirchfieldKernelCPU::operator(), kKernelSize = 4 hard-coded at :175).
+ *
+ * Quirk kept: the CPU functor indexes the scanline accessor
+ * with the +1-shifted indices of the CUDA functor's padded shared-memory
+ * copy, so the "centre" sample of tap p is flat element y*W + p + 1 and its
+ * neighbours are y*W + p and y*W + p + 2; near the row end this reads into
+ * the next row and, on the last row, up to two floats past the image.  The
+ * reference is pinned by giving it images that are views over buffers with
+ * two trailing zero floats; this restatement reads the same flat buffer and
+ * treats flat indices >= H*W as 0.0f, which is the same thing.
+ *
+ * Quirk kept (Q8): entries d > x are not written at all.
+ * get_min/get_max are fmin/fmax chains (include/stereomatch/numeric.hpp:52-65).
+ * ---------------------------------------------------------------------- */
+static inline float flat_at(const float *img, size_t n, size_t idx) {
+  return idx < n ? img[idx] : 0.0f;
+}
+
+static inline float bt_term(const float *L, const float *R, size_t n,
+                            size_t lbase, size_t rbase) {
+  /* lbase = y*W + p + 1, rbase = y*W + p - d + 1 (both >= 1). */
+  const float l = flat_at(L, n, lbase);
+  const float r = flat_at(R, n, rbase);
+  const float la = 0.5f * (l + flat_at(L, n, lbase - 1));
+  const float lb = 0.5f * (l + flat_at(L, n, lbase + 1));
+  const float ra = 0.5f * (r + flat_at(R, n, rbase - 1));
+  const float rb = 0.5f * (r + flat_at(R, n, rbase + 1));
+  const float lmi = fminf(la, fminf(lb, l));
+  const float lma = fmaxf(la, fmaxf(lb, l));
+  const float rmi = fminf(ra, fminf(rb, r));
+  const float rma = fmaxf(ra, fmaxf(rb, r));
+  const float a = fmaxf(0.0f, fmaxf(l - rma, rmi - l));
+  const float b = fmaxf(0.0f, fmaxf(r - lma, lmi - r));
+  return b < a ? b : a; /* min(a, b) */
+}
+
+int orc_birchfield_f32(const float *L, const float *R, float *C, int H, int W,
+                       int D) {
+  if (!L || !R || !C || H <= 0 || W <= 0 || D <= 0) return ORC_EINVAL;
+  const int K = 4;
+  const size_t n = (size_t)H * W;
+  for (int y = 0; y < H; ++y) {
+    for (int x = 0; x < W; ++x) {
+      float *out = C + ((size_t)y * W + x) * D;
+      const int dmax = imin(D, x + 1);
+      for (int disp = 0; disp < dmax; ++disp) {
+        const int start = imax(0, x - disp - K) + disp;
+        const int end = imin(W, x + K);
+        float cost = 0.0f;
+        for (int p = start; p < end; ++p) {
+          const size_t lbase = (size_t)y * W + (size_t)p + 1;
+          const size_t rbase = (size_t)y * W + (size_t)(p - disp) + 1;
+          cost = cost + bt_term(L, R, n, lbase, rbase);
+        }
+        out[disp] = cost;
+      }
+    }
+  }
+  return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------
+ * Semiglobal aggregation.
+ *   path table : src/semiglobal.cpp:18-91 (SGPixelPath::GeneratePaths)
+ *   recurrence : src/semiglobal.cpp:116-159 (SGMCostOperator::operator())
+ *   driver     : src/semiglobal.cpp:191-194 (path, then path.inverse())
+ *   inverse()  : src/semiglobal.hpp:42-45 (swap start/end, negate direction)
+ *
+ * Quirks kept: Q5 (BorderedBuffer::end() is array.end()-1,
+ * src/bordered_buffer.hpp:26-27, so the "minimum of the previous costs"
+ * skips the last disparity), Q6 (the stored end point is wrong for diagonals
+ * clipped by the far image side, so some inverse passes re-walk one corner
+ * diagonal and others never run), Q4 (accumulation in table order).
+ * Coordinates are int16_t like the reference (src/semiglobal.hpp:34-36).
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  int16_t sx, sy, ex, ey, dx, dy;
+  uint16_t size;
+} orc_path;
+
+static size_t orc_num_paths(int W, int H) {
+  return (size_t)H + (size_t)W + 2 * ((size_t)W + (size_t)H - 1);
+}
+
+static void orc_generate_paths(int W, int H, orc_path *out) {
+  size_t n = 0;
+  /* horizontal, semiglobal.cpp:25-29 */
+  for (int i = 0; i < H; ++i) {
+    orc_path p = {0, (int16_t)i, (int16_t)(W - 1), (int16_t)i, 1, 0,
+                  (uint16_t)(int16_t)W};
+    out[n++] = p;
+  }
+  /* vertical, :34-38 */
+  for (int i = 0; i < W; ++i) {
+    orc_path p = {(int16_t)i, 0, (int16_t)i, (int16_t)(H - 1), 0, 1,
+                  (uint16_t)(int16_t)H};
+    out[n++] = p;
+  }
+  /* diagonal left to right, first family, :45-50 */
+  for (int i = 0; i < W; ++i) {
+    const int16_t sx = (int16_t)(W - 1 - i), sy = 0;
+    const int16_t ex = (int16_t)(W - 1), ey = (int16_t)imin(i, H - 1);
+    orc_path p = {sx, sy, ex, ey, 1, 1, (uint16_t)(int16_t)(ey - sy + 1)};
+    out[n++] = p;
+  }
+  /* second family, :52-61 */
+  for (int i = 0; i < H - 1; ++i) {
+    const int16_t sx = 0, sy = (int16_t)(i + 1);
+    const int16_t ex = (int16_t)imin(H - 1 - (i + 1), W - 1);
+    const int16_t ey = (int16_t)(H - 1);
+    orc_path p = {sx, sy, ex, ey, 1, 1, (uint16_t)(int16_t)(ex - sx + 1)};
+    out[n++] = p;
+  }
+  /* diagonal right to left, first family, :66-74 */
+  for (int i = 0; i < W; ++i) {
+    const int diag = imin(i + 1, H);
+    orc_path p = {(int16_t)i, 0, 0, (int16_t)(diag - 1), -1, 1,
+                  (uint16_t)(int16_t)diag};
+    out[n++] = p;
+  }
+  /* second family, :76-89 */
+  for (int i = 0; i < H - 1; ++i) {
+    const int sx = W - 1, sy = i + 1;
+    const int diag = imin(H - (i + 1), W);
+    orc_path p = {(int16_t)sx, (int16_t)sy, (int16_t)(sx - diag + 1),
+                  (int16_t)(sy + diag - 1), -1, 1, (uint16_t)(int16_t)diag};
+    out[n++] = p;
+  }
+}
+
+/* Export of the table for tests (coverage enumeration of Q6). */
+size_t orc_sgm_num_paths(int W, int H) { return orc_num_paths(W, H); }
+int orc_sgm_paths(int W, int H, int16_t *out7) {
+  const size_t n = orc_num_paths(W, H);
+  orc_path *tab = (orc_path *)malloc(n * sizeof(orc_path));
+  if (!tab) return ORC_ENOMEM;
+  orc_generate_paths(W, H, tab);
+  for (size_t i = 0; i < n; ++i) {
+    out7[7 * i + 0] = tab[i].sx;
+    out7[7 * i + 1] = tab[i].sy;
+    out7[7 * i + 2] = tab[i].ex;
+    out7[7 * i + 3] = tab[i].ey;
+    out7[7 * i + 4] = tab[i].dx;
+    out7[7 * i + 5] = tab[i].dy;
+    out7[7 * i + 6] = (int16_t)tab[i].size;
+  }
+  free(tab);
+  return ORC_OK;
+}
+
+typedef struct {
+  const float *C;
+  const float *I;
+  float *S;
+  int H, W, D;
+  float p1, p2;
+  float *prev; /* D + 2 floats, prev[0] and prev[D+1] are +inf borders */
+  float *cur;
+} orc_sgm_ctx;
+
+static void orc_sgm_run(orc_sgm_ctx *c, int sx, int sy, int dx, int dy,
+                        int size) {
+  const int D = c->D;
+  int x = sx, y = sy;
+  {
+    const float *cv = c->C + ((size_t)y * c->W + x) * D;
+    float *sv = c->S + ((size_t)y * c->W + x) * D;
+    for (int d = 0; d < D; ++d) {
+      const float v = cv[d];
+      c->prev[d + 1] = v;
+      sv[d] = sv[d] + v;
+    }
+  }
+  float prev_i = c->I[(size_t)y * c->W + x];
+  for (int i = 1; i < size; ++i) {
+    /* min over d in [0, D-2] (Q5); std::min_element keeps the first. */
+    float m;
+    if (D >= 2) {
+      m = c->prev[1];
+      for (int d = 1; d < D - 1; ++d)
+        if (c->prev[d + 1] < m) m = c->prev[d + 1];
+    } else {
+      m = c->prev[1]; /* empty range: iterator == end() -> element D-1 */
+    }
+    x += dx;
+    y += dy;
+    const float inten = c->I[(size_t)y * c->W + x];
+    const float q = c->p2 / fabsf(inten - prev_i);
+    const float p2a = c->p1 < q ? q : c->p1; /* std::max(p1, q) */
+    prev_i = inten;
+    const float *cv = c->C + ((size_t)y * c->W + x) * D;
+    float *sv = c->S + ((size_t)y * c->W + x) * D;
+    const float far = m + p2a;
+    for (int d = 0; d < D; ++d) {
+      /* get_min(head, tail...): strict '<' in argument order, cpp:11-16 */
+      float t = c->prev[d + 1];
+      const float lo = c->prev[d] + c->p1;
+      const float hi = c->prev[d + 2] + c->p1;
+      if (lo < t) t = lo;
+      if (hi < t) t = hi;
+      if (far < t) t = far;
+      const float a = cv[d] + t;
+      const float l = a - m;
+      sv[d] = sv[d] + l;
+      c->cur[d + 1] = l;
+    }
+    float *tmp = c->prev;
+    c->prev = c->cur;
+    c->cur = tmp;
+  }
+}
+
+/* S must be pre-zeroed by the caller to reproduce Semiglobal.__call__
+ * (stereomatch/aggregation.py:51 -> zeros_tensor_like); the routine
+ * accumulates into it exactly like AggregationOps::RunSemiglobal. */
+int orc_sgm_f32(const float *C, const float *I, float *S, int H, int W, int D,
+                float p1, float p2) {
+  if (!C || !I || !S || H <= 0 || W <= 0 || D <= 0) return ORC_EINVAL;
+  if (W >= 32768 || H >= 32768) return ORC_EINVAL;
+  const size_t n = orc_num_paths(W, H);
+  orc_path *tab = (orc_path *)malloc(n * sizeof(orc_path));
+  float *b0 = (float *)malloc((size_t)(D + 2) * sizeof(float));
+  float *b1 = (float *)malloc((size_t)(D + 2) * sizeof(float));
+  if (!tab || !b0 || !b1) {
+    free(tab);
+    free(b0);
+    free(b1);
+    return ORC_ENOMEM;
+  }
+  orc_generate_paths(W, H, tab);
+  for (int d = 0; d < D + 2; ++d) b0[d] = b1[d] = INFINITY;
+  orc_sgm_ctx ctx = {C, I, S, H, W, D, p1, p2, b0, b1};
+  for (size_t i = 0; i < n; ++i) {
+    const orc_path *p = &tab[i];
+    orc_sgm_run(&ctx, p->sx, p->sy, p->dx, p->dy, p->size);
+    orc_sgm_run(&ctx, p->ex, p->ey, -p->dx, -p->dy, p->size);
+  }
+  free(tab);
+  free(b0);
+  free(b1);
+  return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------
+ * Winner takes all.  src/winners_take_all.cu:21-40 (WTAKernel<kCPU>):
+ * strict '<' scan, lowest index wins ties.
+ * ---------------------------------------------------------------------- */
+int orc_wta_f32(const float *S, int32_t *disp, int H, int W, int D) {
+  if (!S || !disp || H <= 0 || W <= 0 || D <= 0) return ORC_EINVAL;
+  const size_t npix = (size_t)H * W;
+  for (size_t p = 0; p < npix; ++p) {
+    const float *v = S + p * D;
+    float best = v[0];
+    int idx = 0;
+    for (int d = 1; d < D; ++d) {
+      if (v[d] < best) {
+        best = v[d];
+        idx = d;
+      }
+    }
+    disp[p] = idx;
+  }
+  return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------
+ * Dynamic programming.  src/dynamic_programming.cu
+ *   forward  : :24-68 (ExpandPathsKernelCPU::operator(), rows in order
+ *              0..H-1 through KernelLauncher<kCPU>::Launch1D)
+ *   end pick : :219   (torch::argmin(row_final_costs, {1}): first minimum)
+ *   backtrack: :166-181 (ReducePathsKernel) + clamp :143-151
+ *
+ * mode 0 = reference (quirks Q11a transposed initial read, Q11b stray
+ *          zero writes into path[d][row][0], Q11c in-place update, Q12
+ *          backtrack reading path[row][col]); needs D <= H and H <= W so
+ *          the transposed accesses stay in bounds (returns ORC_EINVAL
+ *          otherwise -- the reference would read out of bounds).
+ * mode 1 = corrected initialisation (prev[d] = C[row][0][d],
+ *          path[row][0][d] = 0); everything else identical.
+ * path must be zero-filled by the caller (Q12 pin); row_final is [H][D].
+ * ---------------------------------------------------------------------- */
+int orc_dp_f32(const float *S, int8_t *path, float *row_final, int32_t *disp,
+               int H, int W, int D, int mode) {
+  if (!S || !path || !row_final || !disp || H <= 0 || W <= 0 || D <= 0)
+    return ORC_EINVAL;
+  if (mode == 0 && !(D <= H && H <= W)) return ORC_EINVAL;
+  float *prev = (float *)malloc((size_t)D * sizeof(float));
+  if (!prev) return ORC_ENOMEM;
+  for (int row = 0; row < H; ++row) {
+    for (int d = 0; d < D; ++d) {
+      if (mode == 0) {
+        path[((size_t)d * W + row) * D + 0] = 0;
+        prev[d] = S[((size_t)d * W + row) * D + 0];
+      } else {
+        path[((size_t)row * W + 0) * D + d] = 0;
+        prev[d] = S[((size_t)row * W + 0) * D + d];
+      }
+    }
+    for (int col = 1; col < W; ++col) {
+      const float *cv = S + ((size_t)row * W + col) * D;
+      int8_t *pv = path + ((size_t)row * W + col) * D;
+      for (int d = 0; d < D; ++d) {
+        const float cur = cv[d];
+        const float c1 = d > 0 ? prev[d - 1] : INFINITY;
+        const float c2 = prev[d];
+        const float c3 = d < D - 1 ? prev[d + 1] : INFINITY;
+        float m;
+        int8_t dir;
+        if (c1 < c2 && c1 < c3) {
+          m = c1;
+          dir = -1;
+        } else if (c2 < c3) {
+          m = c2;
+          dir = 0;
+        } else {
+          m = c3;
+          dir = 1;
+        }
+        pv[d] = dir;
+        prev[d] = cur + m;
+      }
+    }
+    for (int d = 0; d < D; ++d) row_final[(size_t)row * D + d] = prev[d];
+  }
+  free(prev);
+  for (int row = 0; row < H; ++row) {
+    const float *rf = row_final + (size_t)row * D;
+    int end = 0;
+    float best = rf[0];
+    for (int d = 1; d < D; ++d) {
+      if (rf[d] < best) {
+        best = rf[d];
+        end = d;
+      }
+    }
+    int cur = end;
+    disp[(size_t)row * W + (W - 1)] = cur;
+    for (int col = W - 2; col >= 0; --col) {
+      const int8_t dir = path[((size_t)row * W + col) * D + cur];
+      cur = cur + dir;
+      if (cur < 0) cur = 0;
+      if (cur > D - 1) cur = D - 1;
+      disp[(size_t)row * W + col] = cur;
+    }
+  }
+  return ORC_OK;
+}
+
+int orc_version(void) { return 1; }
