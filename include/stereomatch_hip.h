@@ -1,0 +1,137 @@
+/*
+ * stereomatch_hip.h -- C ABI of libstereomatch_hip.so, the MI355X (gfx950)
+ * implementation of the stereo cost-volume hot path.
+ *
+ * Each entry point replaces one static method of the reference's pybind11
+ * extension `stereomatch._cstereomatch` (upstream src/_cstereomatch.cpp:10-17):
+ *
+ *   stm_ssd_f32         <- CostOps.compute_ssd            src/cost.cpp:6-9,  include/stereomatch/cost.hpp:10-13, src/ssd.cu:64-81
+ *   stm_birchfield_f32  <- CostOps.compute_birchfield     src/cost.cpp:14,   include/stereomatch/cost.hpp:19-22, src/birchfield_cost.cu:153-181
+ *   stm_sgm_f32         <- AggregationOps.run_semiglobal  src/aggregation.cpp:6, include/stereomatch/aggregation.hpp:8-10, src/semiglobal.cpp:167-197
+ *   stm_wta_f32         <- DisparityReduceOps.run_winners_take_all    src/disparity_reduce.cpp:6-7, include/stereomatch/disparity_reduce.hpp:8-9, src/winners_take_all.cu:89-114
+ *   stm_dp_f32          <- DisparityReduceOps.run_dynamic_programming src/disparity_reduce.cpp:8-9, include/stereomatch/disparity_reduce.hpp:10-13, src/dynamic_programming.cu:184-225
+ *
+ * Conventions
+ *  - Plain pointers and sizes only; no torch types.  All pointers are DEVICE
+ *    pointers on the current HIP device unless stated otherwise.
+ *  - Images are [batch][H][W] float32, volumes [batch][H][W][D] float32 with D
+ *    innermost, disparity maps [batch][H][W] int32, all contiguous.  batch >= 1
+ *    processes independent stereo pairs in one launch sequence (the reference
+ *    has no batch axis; batch == 1 is its exact call shape).
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Work is
+ *    enqueued stream-ordered; no entry point synchronises the device,
+ *    allocates device memory or copies to/from the host, so all of them can be
+ *    captured into a hipGraph.
+ *  - The library keeps no state between calls.  Scratch memory, where needed,
+ *    is supplied by the caller (`workspace`, sized by *_workspace_bytes).
+ *  - Return value: STM_OK or an STM_E* code; stm_last_error() then returns a
+ *    thread-local, human-readable message (the Python wrappers raise
+ *    RuntimeError with it, matching the reference's std::runtime_error ->
+ *    RuntimeError convention, include/stereomatch/check.hpp:12-19).
+ *  - Results are the reference CPU path's, bit for bit (see DESIGN.md for the
+ *    quirks this includes); floating-point contraction is disabled in the
+ *    device code.
+ */
+#ifndef STEREOMATCH_HIP_H_
+#define STEREOMATCH_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STM_ABI_VERSION 1
+
+#define STM_OK 0
+#define STM_EINVAL 1       /* bad argument (null pointer, non-positive size, misalignment) */
+#define STM_EUNSUPPORTED 2 /* valid but outside what the kernels cover (e.g. D > 1024) */
+#define STM_EHIP 3         /* a HIP runtime call or kernel launch failed */
+#define STM_EWORKSPACE 4   /* workspace missing or too small */
+
+/* Largest disparity range the wave-per-path / wave-per-pixel kernels cover
+ * (64 lanes x 16 values).  The reference's CUDA path stops at 1024 as well
+ * (one thread per disparity, src/semiglobal_gpu.cu:109-120). */
+#define STM_MAX_DISPARITY 1024
+
+int stm_abi_version(void);
+const char *stm_last_error(void);
+
+/* ---- SSD cost volume (src/ssd.cu:31-61) ------------------------------------
+ * cost[r][c][d] = sum over rows [max(r-k,0), min(r+k,H)) and columns
+ * [max(c-k,d), min(c+k,W)) of (L - R shifted by d)^2 in row-major order with
+ * separate multiply and add; +inf for d > c.  k = kernel_size (reference
+ * default 7).
+ *
+ * mode:
+ *   STM_SSD_ORDERED  every output is the reference's ordered 4k^2-tap sum:
+ *                    bit-exact for any input.
+ *   STM_SSD_BOX      separable box sums (vertical then sliding horizontal).
+ *                    Bit-exact only when every partial sum is an exactly
+ *                    representable integer, i.e. integer-valued images with
+ *                    (2k)^2 * (value range)^2 <= 2^24 (e.g. 8-bit images, k<=8).
+ *   STM_SSD_AUTO     a device-side classifier checks that condition on the
+ *                    actual images and picks BOX when it holds, ORDERED
+ *                    otherwise; results are bit-exact either way.  Needs a
+ *                    workspace of stm_ssd_workspace_bytes().
+ */
+#define STM_SSD_AUTO 0
+#define STM_SSD_ORDERED 1
+#define STM_SSD_BOX 2
+size_t stm_ssd_workspace_bytes(int H, int W, int D, int kernel_size, int batch);
+int stm_ssd_f32(const float *left, const float *right, float *cost, int H,
+                int W, int D, int kernel_size, int mode, void *workspace,
+                size_t workspace_bytes, int batch, void *stream);
+
+/* ---- Birchfield-Tomasi cost (src/birchfield_cost.cu:26-67) -------------------
+ * 8-tap window (the reference hard-codes kKernelSize = 4 and ignores the
+ * kernel_size argument, :167,175).  Follows the CPU functor including its
+ * +1-shifted sample indexing; flat indices past the end of an image read as
+ * 0.0f (the reference reads out of bounds there).  Entries d > x are left
+ * untouched, as in the reference.
+ */
+int stm_birchfield_f32(const float *left, const float *right, float *cost,
+                       int H, int W, int D, int batch, void *stream);
+
+/* ---- Semiglobal aggregation (src/semiglobal.cpp:18-160,167-197) ----------------
+ * out = sum over the reference's path passes of L_r, accumulated in the
+ * reference's path-table order (8 directions, including its quirks for the
+ * two inverse-diagonal families and the min-over-[0,D-2] term).
+ *
+ * flags:
+ *   STM_SGM_ACCUMULATE  out += ... on top of the caller's contents (the
+ *                       reference semantics on a pre-zeroed tensor).  Without
+ *                       it `out` is overwritten, which is identical to
+ *                       accumulating into zeros and saves one read of `out`.
+ */
+#define STM_SGM_ACCUMULATE 1
+size_t stm_sgm_workspace_bytes(int H, int W, int D, int batch, int flags);
+int stm_sgm_f32(const float *cost, const float *left, float *out, int H, int W,
+                int D, float penalty1, float penalty2, int flags,
+                void *workspace, size_t workspace_bytes, int batch,
+                void *stream);
+
+/* ---- Winner takes all (src/winners_take_all.cu:21-40) -------------------------
+ * disparity[r][c] = index of the first minimum over d (strict '<' scan). */
+int stm_wta_f32(const float *volume, int32_t *disparity, int H, int W, int D,
+                int batch, void *stream);
+
+/* ---- Dynamic programming (src/dynamic_programming.cu:24-68,166-181) ------------
+ * path      [batch][H][W][D] int8  (scratch + output; fully written)
+ * row_final [batch][H][D] float32  (output)
+ * mode STM_DP_REFERENCE reproduces the CPU functor including its transposed
+ * initial read (requires D <= H <= W, else STM_EINVAL) with the path volume
+ * treated as zero-filled; STM_DP_CORRECTED initialises from column 0 of the
+ * same row instead.
+ */
+#define STM_DP_REFERENCE 0
+#define STM_DP_CORRECTED 1
+int stm_dp_f32(const float *volume, int8_t *path, float *row_final,
+               int32_t *disparity, int H, int W, int D, int mode, int batch,
+               void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STEREOMATCH_HIP_H_ */

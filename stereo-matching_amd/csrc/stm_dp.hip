@@ -1,0 +1,288 @@
+// Scanline dynamic programming: forward pass, end-disparity pick, backtrack.
+//
+// Reference semantics (CPU path): src/dynamic_programming.cu
+//   forward   :24-68   per row: prev[d] initialised (transposed read, see below), then for
+//                      col = 1..W-1, for d = 0..D-1 IN PLACE:
+//                        c1 = d > 0 ? prev[d-1] (already updated) : inf; c2 = prev[d];
+//                        c3 = d < D-1 ? prev[d+1] : inf
+//                        (c1 < c2 && c1 < c3) -> (c1,-1); else c2 < c3 -> (c2, 0); else (c3,+1)
+//                        path[row][col][d] = dir; prev[d] = cost[row][col][d] + m
+//   end pick  :219     torch::argmin(row_final, 1): first minimum
+//   backtrack :166-181 cur = end; disp[row][W-1] = cur; for col = W-2..0:
+//                        cur = clamp(cur + path[row][col][cur], 0, D-1); disp[row][col] = cur
+//
+// Quirks kept in STM_DP_REFERENCE mode:
+//   Q11a  the initial read is cost[d][row][0] (indices transposed)      -> needs D <= H <= W
+//   Q11b  the initialisation writes path[d][row][0] = 0, which clobbers entries that
+//         earlier rows already produced: after all rows, path[r][c][0] = 0 for
+//         r < D, r < c < H.  Rows are independent otherwise, so the clobber is applied
+//         as a separate tiny kernel after the forward pass instead of serialising rows.
+//   Q12   the backtrack reads path[row][col] (not col+1) and so consumes column 0,
+//         which the forward pass never computes; it is defined as zero here (the
+//         reference leaves it to torch.empty; its pinned form zero-fills).
+//
+// The in-place d loop is a serial (min,+) chain with a rounded add at every link, so a
+// scan would re-associate the adds.  It is parallelised exactly instead: with
+// m23[d] = (c2 < c3 ? c2 : c3) the update is new[d] = cost[d] + (new[d-1] < m23[d] ?
+// new[d-1] : m23[d]); starting from new[d] = cost[d] + m23[d] and re-applying that map
+// until nothing changes reaches the chain's unique fixed point with the very same
+// floating-point operations (each link is evaluated with its final inputs exactly
+// once more than needed).  Chains are short in practice (a link is taken only where
+// the lower neighbour's new cost undercuts both old costs), so a column costs a few
+// wave-parallel sweeps instead of D dependent steps.
+//
+// Design: one wave per image row; lane l holds disparities l*VPL .. l*VPL+VPL-1.
+// Bound: HBM, 4 bytes read + 1 byte written per (pixel, d) in the forward pass.
+#include "stm_common.h"
+
+namespace stm {
+namespace {
+
+constexpr int kDpBlock = 256;
+constexpr int kDpPF = 4;
+
+struct DpShape {
+  int H, W, D, mode, batch;
+};
+
+template <int VPL, bool VEC>
+__global__ __launch_bounds__(kDpBlock) void dp_forward_kernel(const float *__restrict__ vol_all,
+                                                              int8_t *__restrict__ path_all,
+                                                              float *__restrict__ rowfin_all,
+                                                              const DpShape S) {
+  const int lane = threadIdx.x & 63;
+  const int wave = wave_uniform((int)(blockIdx.x * (kDpBlock / 64) + (threadIdx.x >> 6)));
+  if (wave >= S.H * S.batch) return;
+  const int b = wave / S.H;
+  const int row = wave - b * S.H;
+  const size_t npix = (size_t)S.H * S.W;
+  const float *vol = vol_all + (size_t)b * npix * S.D;
+  int8_t *path = path_all + (size_t)b * npix * S.D;
+  float *rowfin = rowfin_all + ((size_t)b * S.H + row) * S.D;
+  const int D = S.D, W = S.W;
+  const int d0 = lane * VPL;
+  const float inf = __builtin_inff();
+
+  float prev[VPL];
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const int d = d0 + j;
+    float v = inf;
+    if (d < D) {
+      v = S.mode == STM_DP_REFERENCE ? vol[((size_t)d * W + row) * D]        // cost[d][row][0]
+                                     : vol[((size_t)row * W) * D + d];      // cost[row][0][d]
+      path[((size_t)row * W) * D + d] = 0;  // column 0 is defined as zero (Q12)
+    }
+    prev[j] = v;
+  }
+
+  // Ring of cost rows in flight.
+  Row<VPL> cbuf[kDpPF];
+  auto fetch = [&](int col, Row<VPL> &dst) {
+    dst = load_row<VPL, VEC>(vol, (size_t)row * W + col, D, d0);
+  };
+#pragma unroll
+  for (int u = 0; u < kDpPF; ++u) fetch(1 + u < W ? 1 + u : W - 1, cbuf[u]);
+
+  for (int base = 1; base < W; base += kDpPF) {
+#pragma unroll
+    for (int u = 0; u < kDpPF; ++u) {
+      const int col = base + u;
+      if (col < W) {
+        float c[VPL];
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) c[j] = cbuf[u].v[j];
+        fetch(col + kDpPF < W ? col + kDpPF : W - 1, cbuf[u]);
+
+        // m23 and the +1 / 0 direction; prev[D] = +inf.
+        const float nxt = lane_down(prev[0], inf);
+        float m23[VPL];
+        bool take2[VPL];
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+          const float c2 = prev[j];
+          float c3 = j + 1 < VPL ? prev[j + 1] : nxt;
+          if (d0 + j >= D - 1) c3 = inf;
+          take2[j] = c2 < c3;
+          m23[j] = take2[j] ? c2 : c3;
+        }
+        // Fixed-point iteration of the in-place chain.
+        float nw[VPL];
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) nw[j] = c[j] + m23[j];
+        float left = inf;
+        for (;;) {
+          left = lane_up(nw[VPL - 1], inf);  // new[d0 - 1]; +inf for d0 == 0
+          bool changed = false;
+          float carry = left;
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) {
+            const float m = carry < m23[j] ? carry : m23[j];
+            const float v = c[j] + m;
+            // Bit compare: a NaN that reproduces itself must not keep the loop alive.
+            changed |= __builtin_bit_cast(int, v) != __builtin_bit_cast(int, nw[j]);
+            nw[j] = v;
+            carry = v;
+          }
+          if (__ballot(changed) == 0ull) break;
+        }
+        // Directions from the final values.
+        int8_t dir[VPL];
+        {
+          float carry = left;
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) {
+            dir[j] = carry < m23[j] ? (int8_t)-1 : (take2[j] ? (int8_t)0 : (int8_t)1);
+            carry = nw[j];
+          }
+        }
+        int8_t *pp = path + ((size_t)row * W + col) * D + d0;
+        if (VPL == 4 && VEC) {
+          if (d0 < D) {
+            const unsigned w = (unsigned)(uint8_t)dir[0] | ((unsigned)(uint8_t)dir[1 % VPL] << 8) |
+                               ((unsigned)(uint8_t)dir[2 % VPL] << 16) |
+                               ((unsigned)(uint8_t)dir[3 % VPL] << 24);
+            *reinterpret_cast<unsigned *>(pp) = w;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < VPL; ++j)
+            if (d0 + j < D) pp[j] = dir[j];
+        }
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) prev[j] = (d0 + j < D) ? nw[j] : inf;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VPL; ++j)
+    if (d0 + j < D) rowfin[d0 + j] = prev[j];
+}
+
+// Q11b: path[r][c][0] = 0 for r < D, r < c < H (and c < W, implied by H <= W).
+__global__ void dp_clobber_kernel(int8_t *__restrict__ path_all, const DpShape S) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y;
+  const int b = blockIdx.z;
+  if (r < S.D && r < S.H && c > r && c < S.H && c < S.W)
+    path_all[(((size_t)b * S.H + r) * S.W + c) * S.D] = 0;
+}
+
+// One wave per row: pick the end disparity, then walk back through the row's path
+// records.  The records of a chunk of columns are pulled into LDS with coalesced
+// loads; lane 0 follows the chain there and the chunk's disparities leave as one
+// coalesced store.
+constexpr int kBtChunk = 64;
+
+__global__ __launch_bounds__(64) void dp_backtrack_kernel(const int8_t *__restrict__ path_all,
+                                                          const float *__restrict__ rowfin_all,
+                                                          int32_t *__restrict__ disp_all,
+                                                          const DpShape S) {
+  extern __shared__ __align__(16) unsigned char dp_smem[];
+  int8_t *tile = reinterpret_cast<int8_t *>(dp_smem);                   // [kBtChunk][D]
+  int *dchunk = reinterpret_cast<int *>(dp_smem + (size_t)kBtChunk * ((S.D + 15) & ~15));
+  const int lane = threadIdx.x;
+  const int row = blockIdx.x;
+  const int b = blockIdx.y;
+  const int D = S.D, W = S.W;
+  const int8_t *path = path_all + (((size_t)b * S.H + row) * W) * D;
+  const float *rf = rowfin_all + ((size_t)b * S.H + row) * D;
+  int32_t *disp = disp_all + ((size_t)b * S.H + row) * W;
+
+  // First minimum of the row's final costs (torch::argmin semantics for non-NaN input).
+  float best = __builtin_inff();
+  int idx = 0x7fffffff;
+  for (int d = lane; d < D; d += 64) {
+    const float q = rf[d];
+    if (idx == 0x7fffffff) idx = d;
+    if (q < best) { best = q; idx = d; }
+  }
+  const float m = group_min_f32<64>(best);
+  int cand = (best == m) ? idx : 0x7fffffff;
+  int cur = group_min_i32<64>(cand);
+  if (cur == 0x7fffffff) cur = 0;  // all-NaN row
+  if (lane == 0) disp[W - 1] = cur;
+
+  // Columns W-2 .. 0 in chunks [lo, hi].
+  for (int hi = W - 2; hi >= 0; hi -= kBtChunk) {
+    const int lo = hi - kBtChunk + 1 > 0 ? hi - kBtChunk + 1 : 0;
+    const int ncol = hi - lo + 1;
+    const size_t bytes = (size_t)ncol * D;
+    const int8_t *src = path + (size_t)lo * D;
+    // Coalesced copy; 16-byte vectors when the chunk start is aligned.
+    if ((((uintptr_t)src) & 15) == 0 && (bytes & 15) == 0) {
+      const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+      uint4 *t4 = reinterpret_cast<uint4 *>(tile);
+      for (size_t i = lane; i < bytes / 16; i += 64) t4[i] = s4[i];
+    } else {
+      for (size_t i = lane; i < bytes; i += 64) tile[i] = src[i];
+    }
+    __syncthreads();
+    if (lane == 0) {
+      for (int col = hi; col >= lo; --col) {
+        cur = cur + (int)tile[(size_t)(col - lo) * D + cur];
+        cur = cur < 0 ? 0 : (cur > D - 1 ? D - 1 : cur);
+        dchunk[col - lo] = cur;
+      }
+    }
+    __syncthreads();
+    cur = __builtin_amdgcn_readfirstlane(cur);
+    if (lane < ncol) disp[lo + lane] = dchunk[lane];
+    __syncthreads();
+  }
+}
+
+}  // namespace
+}  // namespace stm
+
+extern "C" int stm_dp_f32(const float *volume, int8_t *path, float *row_final, int32_t *disparity,
+                          int H, int W, int D, int mode, int batch, void *stream) {
+  using namespace stm;
+  STM_REQUIRE(volume && path && row_final && disparity, STM_EINVAL, "stm_dp_f32: null pointer");
+  STM_REQUIRE(H > 0 && W > 0 && D > 0 && batch > 0, STM_EINVAL,
+              "stm_dp_f32: non-positive size (H=%d W=%d D=%d batch=%d)", H, W, D, batch);
+  STM_REQUIRE(mode == STM_DP_REFERENCE || mode == STM_DP_CORRECTED, STM_EINVAL,
+              "stm_dp_f32: unknown mode %d", mode);
+  STM_REQUIRE(D <= STM_MAX_DISPARITY, STM_EUNSUPPORTED, "stm_dp_f32: D=%d exceeds %d", D,
+              STM_MAX_DISPARITY);
+  if (mode == STM_DP_REFERENCE)
+    STM_REQUIRE(D <= H && H <= W, STM_EINVAL,
+                "stm_dp_f32: reference mode reads cost[d][row][0] and needs D <= H <= W "
+                "(got H=%d W=%d D=%d); use STM_DP_CORRECTED", H, W, D);
+  STM_REQUIRE(H <= 65535 && batch <= 65535, STM_EUNSUPPORTED, "stm_dp_f32: H or batch exceeds the grid limit");
+  hipStream_t s = as_stream(stream);
+  DpShape S;
+  S.H = H; S.W = W; S.D = D; S.mode = mode; S.batch = batch;
+  const int vpl = (D + 63) / 64;
+  int VPL = 1;
+  while (VPL < vpl) VPL <<= 1;
+  const int waves = H * batch;
+  const dim3 grid((waves + kDpBlock / 64 - 1) / (kDpBlock / 64)), block(kDpBlock);
+  const uintptr_t align = VPL >= 4 ? 15 : (VPL == 2 ? 7 : 3);
+  const bool vec = (D == VPL * 64) && ((reinterpret_cast<uintptr_t>(volume) & align) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(path) & 3) == 0);
+#define STM_DP_LAUNCH(V)                                                                              \
+  do {                                                                                                \
+    if (vec) hipLaunchKernelGGL((dp_forward_kernel<V, true>), grid, block, 0, s, volume, path, row_final, S); \
+    else hipLaunchKernelGGL((dp_forward_kernel<V, false>), grid, block, 0, s, volume, path, row_final, S);    \
+  } while (0)
+  switch (VPL) {
+    case 1: STM_DP_LAUNCH(1); break;
+    case 2: STM_DP_LAUNCH(2); break;
+    case 4: STM_DP_LAUNCH(4); break;
+    case 8: STM_DP_LAUNCH(8); break;
+    default: STM_DP_LAUNCH(16); break;
+  }
+#undef STM_DP_LAUNCH
+  int rc = check_launch("stm_dp_f32 (forward)");
+  if (rc != STM_OK) return rc;
+  if (mode == STM_DP_REFERENCE && H > 1) {
+    const int rows = D < H ? D : H;
+    hipLaunchKernelGGL(dp_clobber_kernel, dim3((H + 255) / 256, rows, batch), dim3(256), 0, s, path, S);
+    rc = check_launch("stm_dp_f32 (clobber)");
+    if (rc != STM_OK) return rc;
+  }
+  const size_t lds = (size_t)kBtChunk * ((D + 15) & ~15) + sizeof(int) * kBtChunk;
+  hipLaunchKernelGGL(dp_backtrack_kernel, dim3(H, batch), dim3(64), lds, s, path, row_final, disparity, S);
+  return check_launch("stm_dp_f32 (backtrack)");
+}

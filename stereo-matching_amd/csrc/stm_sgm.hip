@@ -1,0 +1,374 @@
+// Semiglobal aggregation, path-parallel: one wavefront walks one path.
+//
+// Reference semantics (CPU path, the parity target):
+//   path table   src/semiglobal.cpp:18-91   (SGPixelPath::GeneratePaths)
+//   recurrence   src/semiglobal.cpp:116-159 (SGMCostOperator::operator())
+//   driver       src/semiglobal.cpp:191-194 (for each path: run(path); run(path.inverse()))
+//   L(p0,d) = C(p0,d)
+//   L(pi,d) = (C(pi,d) + min{ L(pi-1,d), L(pi-1,d-1)+P1, L(pi-1,d+1)+P1, m+P2' }) - m
+//   m   = min over d in [0, D-2] of L(pi-1,d)      (BorderedBuffer::end() quirk, src/bordered_buffer.hpp:26-27)
+//   P2' = max(P1, P2 / |I(pi) - I(pi-1)|)
+//   out(p,d) += L(p,d) for every visit, in path-table order.
+//
+// Design for gfx950
+//   * The disparity axis lives in the 64 lanes of a wave: lane l holds the
+//     VPL = ceil(D/64) consecutive disparities l*VPL..l*VPL+VPL-1 of the previous
+//     pixel in registers, so each pixel is one contiguous 4*D-byte burst (16 B
+//     per lane at D = 256) and the d-1 / d+1 neighbours are a register move or
+//     one DPP wave shift.  m is a DPP min-reduction with the d = D-1 element
+//     masked out.
+//   * The path table is never materialised: every launch covers one of the
+//     eight direction families and each wave derives its start, step and length
+//     from its index in closed form (the reference rebuilds and, on CUDA,
+//     re-uploads the table on every call, src/semiglobal_gpu.cu:126-127).
+//   * The accumulation order of the reference (->, <-, down, up, then the two
+//     diagonal pairs) is kept by running the eight families as eight
+//     stream-ordered launches; inside one launch every output element has
+//     exactly one writer, so there are no atomics and the float sums are the
+//     reference's bit for bit.  The reference's mis-stored diagonal end points
+//      turn into "skip this inverse pass" / "repeat this one
+//     n times" flags computed from the path index.
+//   * Memory latency along the sequential walk is hidden by a register ring
+//     that keeps PF pixels of cost and output rows in flight per wave.
+//
+// Bound: HBM.  Per pass 4N bytes of cost are read and 4N (first pass: write
+// only) or 8N bytes of the running sum are moved, N = H*W*D: 92N in total
+// against the algorithmic 8N (read cost once, write sum once).
+#include "stm_common.h"
+
+namespace stm {
+namespace {
+
+constexpr int kSgmBlock = 256;
+constexpr int kPF = 4;  // pixels kept in flight per wave
+
+enum Family : int {
+  kRight = 0,      // group 1 forward   (1, 0)
+  kLeft = 1,       // group 1 inverse   (-1, 0)
+  kDown = 2,       // group 2 forward   (0, 1)
+  kUp = 3,         // group 2 inverse   (0, -1)
+  kDownRight = 4,  // groups 3+4 forward (1, 1)
+  kUpLeft = 5,     // groups 3+4 inverse (-1, -1)
+  kDownLeft = 6,   // groups 5+6 forward (-1, 1)
+  kUpRight = 7,    // groups 5+6 inverse (1, -1)
+};
+
+struct Walk {
+  int x0, y0, dx, dy, len;
+  int repeat;  // how many times each L is added (0 = the reference never runs this pass)
+};
+
+__host__ __device__ inline int sgm_family_paths(int family, int H, int W) {
+  switch (family) {
+    case kRight: case kLeft: return H;
+    case kDown: case kUp: return W;
+    default: return W + H - 1;
+  }
+}
+
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+
+// Start, direction, length and repeat count of path `w` of a family, following
+// GeneratePaths and SGPixelPath::inverse() (src/semiglobal.hpp:42-45) entry by
+// entry.  `pre` receives the walk that has to run *before* this one on the same
+// wave (tall images only, see below).
+__device__ __forceinline__ Walk sgm_decode(int family, int w, int H, int W, Walk *pre) {
+  Walk k;
+  k.repeat = 1;
+  pre->repeat = 0;
+  switch (family) {
+    case kRight: k = {0, w, 1, 0, W, 1}; break;
+    case kLeft: k = {W - 1, w, -1, 0, W, 1}; break;
+    case kDown: k = {w, 0, 0, 1, H, 1}; break;
+    case kUp: k = {w, H - 1, 0, -1, H, 1}; break;
+    case kDownRight:
+      if (w < W) {  // semiglobal.cpp:45-50
+        k = {W - 1 - w, 0, 1, 1, imin(w, H - 1) + 1, 1};
+      } else {      // :52-61
+        const int i = w - W;
+        k = {0, i + 1, 1, 1, imin(H - 2 - i, W - 1) + 1, 1};
+        // Tall images: the inverses of paths i < H-W-1 of this group start at the
+        // wrong stored end (W-1, H-1) and so re-walk the diagonal that belongs to
+        // path i = H-W-1, *before* that path's own forward pass in table order.
+        if (H > W + 1 && i == H - W - 1) *pre = {W - 1, H - 1, -1, -1, W, H - W - 1};
+      }
+      break;
+    case kUpLeft:
+      if (w < W) {
+        const int ey = imin(w, H - 1);
+        k = {W - 1, ey, -1, -1, ey + 1, 1};
+        // Wide images: for w >= H the stored end is (W-1, H-1) instead of the true
+        // end, so those passes all re-walk the diagonal of path w = H-1.
+        if (w >= H) k.repeat = 0;
+        else if (w == H - 1 && W > H) k.repeat = W - H + 1;
+      } else {
+        const int i = w - W;
+        const int ex = imin(H - 2 - i, W - 1);
+        k = {ex, H - 1, -1, -1, ex + 1, 1};
+        if (W - 1 < H - 2 - i) k.repeat = 0;  // re-walks handled by the `pre` walk above
+      }
+      break;
+    case kDownLeft:
+      if (w < W) {  // :66-74
+        k = {w, 0, -1, 1, imin(w + 1, H), 1};
+      } else {      // :76-89
+        const int i = w - W;
+        k = {W - 1, i + 1, -1, 1, imin(H - (i + 1), W), 1};
+      }
+      break;
+    default:  // kUpRight
+      if (w < W) {
+        const int len = imin(w + 1, H);
+        k = {0, len - 1, 1, -1, len, 1};
+        if (w >= H) k.repeat = 0;  // stored end (0, H-1) is wrong: duplicates of w = H-1
+        else if (w == H - 1 && W > H) k.repeat = W - H + 1;
+      } else {
+        const int i = w - W;
+        const int len = imin(H - (i + 1), W);
+        k = {W - len, i + len, 1, -1, len, 1};
+      }
+      break;
+  }
+  return k;
+}
+
+// One pass along one path.  FIRST: the output row is overwritten with
+// 0 + L (what accumulating into a zero-filled tensor gives) instead of
+// read-modify-written.
+template <int VPL, bool VEC, bool FIRST>
+struct Walker {
+  const float *__restrict__ cost;
+  const float *__restrict__ image;
+  float *__restrict__ out;
+  int D, d0;
+  float p1, p2;
+  Row<VPL> prev;
+  float prev_i;
+
+  __device__ __forceinline__ void fetch(long q, Row<VPL> &c, Row<VPL> &s, float &inten) const {
+    c = load_row<VPL, VEC>(cost, (size_t)q, D, d0);
+    if constexpr (!FIRST) s = load_row<VPL, VEC>(out, (size_t)q, D, d0);
+    inten = image[q];
+  }
+
+  // Pixel i > 0 of the path: semiglobal.cpp:129-157.
+  __device__ __forceinline__ Row<VPL> advance(const Row<VPL> &c, float inten) const {
+    const float inf = __builtin_inff();
+    // m over d in [0, D-2]: the element d = D-1 is left out (Q5).
+    float lm = inf;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j)
+      if (d0 + j < D - 1) lm = fminf(lm, prev.v[j]);
+    float m = wave_min_f32(lm);
+    if (D == 1) m = read_lane(prev.v[0], 0);  // empty range: *end() is element D-1
+    const float q = p2 / fabsf(inten - prev_i);
+    const float p2a = p1 < q ? q : p1;  // std::max(p1, q)
+    const float far = m + p2a;
+    const float below = lane_up(prev.v[VPL - 1], inf);  // L(d0-1)
+    const float above = lane_down(prev.v[0], inf);      // L(d0+VPL)
+    Row<VPL> cur;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+      const float lo = (j == 0 ? below : prev.v[j - 1]) + p1;
+      const float hi = (j == VPL - 1 ? above : prev.v[j + 1]) + p1;
+      float t = prev.v[j];
+      t = lo < t ? lo : t;  // get_min: strict '<' in argument order (cpp:11-16)
+      t = hi < t ? hi : t;
+      t = far < t ? far : t;
+      const float a = c.v[j] + t;
+      cur.v[j] = a - m;
+    }
+    return cur;
+  }
+
+  __device__ __forceinline__ void emit(long q, const Row<VPL> &s, const Row<VPL> &cur,
+                                       int repeat) const {
+    Row<VPL> o;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) o.v[j] = (FIRST ? 0.0f : s.v[j]) + cur.v[j];
+    for (int r = 1; r < repeat; ++r) {  // re-walked diagonals only (Q6)
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) o.v[j] = o.v[j] + cur.v[j];
+    }
+    store_row<VPL, VEC>(out, (size_t)q, D, d0, o);
+  }
+
+  __device__ __forceinline__ void run(const Walk k, int W) {
+    const long step = (long)k.dy * W + k.dx;
+    long pix = (long)k.y0 * W + k.x0;
+    const int last = k.len - 1;
+
+    Row<VPL> cbuf[kPF], sbuf[kPF];
+    float ibuf[kPF];
+    // Ring slot u holds pixel i with i % kPF == u; loads past the end of the
+    // path re-read its last pixel so that the loop body is branch-free.
+#pragma unroll
+    for (int u = 0; u < kPF; ++u) fetch(pix + (long)imin(u, last) * step, cbuf[u], sbuf[u], ibuf[u]);
+
+    // Pixel 0: L = C (semiglobal.cpp:123-127).
+    {
+      const Row<VPL> c = cbuf[0];
+      const Row<VPL> s = sbuf[0];
+      prev_i = ibuf[0];
+      fetch(pix + (long)imin(kPF, last) * step, cbuf[0], sbuf[0], ibuf[0]);
+      emit(pix, s, c, k.repeat);
+      prev = c;
+      pix += step;
+    }
+    int i = 1;
+    // Pixels 1 .. kPF-1 bring the ring into phase.
+#pragma unroll
+    for (int u = 1; u < kPF; ++u) {
+      if (i < k.len) {
+        const Row<VPL> c = cbuf[u];
+        const Row<VPL> s = sbuf[u];
+        const float inten = ibuf[u];
+        fetch(pix + (long)imin(kPF, last - i) * step, cbuf[u], sbuf[u], ibuf[u]);
+        const Row<VPL> cur = advance(c, inten);
+        emit(pix, s, cur, k.repeat);
+        prev = cur;
+        prev_i = inten;
+        pix += step;
+        ++i;
+      }
+    }
+    // Steady state: kPF pixels per trip, every slot consumed and refilled.
+    for (; i + kPF <= k.len; i += kPF) {
+#pragma unroll
+      for (int u = 0; u < kPF; ++u) {
+        const Row<VPL> c = cbuf[u];
+        const Row<VPL> s = sbuf[u];
+        const float inten = ibuf[u];
+        fetch(pix + (long)imin(kPF, last - (i + u)) * step, cbuf[u], sbuf[u], ibuf[u]);
+        const Row<VPL> cur = advance(c, inten);
+        emit(pix, s, cur, k.repeat);
+        prev = cur;
+        prev_i = inten;
+        pix += step;
+      }
+    }
+    // Tail: fewer than kPF pixels left, already in the ring.
+#pragma unroll
+    for (int u = 0; u < kPF - 1; ++u) {
+      if (i < k.len) {
+        const Row<VPL> cur = advance(cbuf[u], ibuf[u]);
+        emit(pix, sbuf[u], cur, k.repeat);
+        prev = cur;
+        prev_i = ibuf[u];
+        pix += step;
+        ++i;
+      }
+    }
+  }
+};
+
+struct SgmShape {
+  int H, W, D;
+  float p1, p2;
+  int family;
+  int paths;  // paths per image in this family
+  int batch;
+};
+
+template <int VPL, bool VEC, bool FIRST>
+__global__ __launch_bounds__(kSgmBlock) void sgm_pass_kernel(const float *__restrict__ cost_all,
+                                                             const float *__restrict__ image_all,
+                                                             float *__restrict__ out_all,
+                                                             const SgmShape P) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = wave_uniform((int)(blockIdx.x * (kSgmBlock / kWave) + (threadIdx.x >> 6)));
+  if (wave >= P.paths * P.batch) return;
+  const int b = wave / P.paths;
+  const int w = wave - b * P.paths;
+  const size_t npix = (size_t)P.H * P.W;
+
+  Walker<VPL, VEC, FIRST> wk;
+  wk.cost = cost_all + (size_t)b * npix * P.D;
+  wk.image = image_all + (size_t)b * npix;
+  wk.out = out_all + (size_t)b * npix * P.D;
+  wk.D = P.D;
+  wk.d0 = lane * VPL;
+  wk.p1 = P.p1;
+  wk.p2 = P.p2;
+
+  Walk pre;
+  const Walk main_walk = sgm_decode(P.family, w, P.H, P.W, &pre);
+#pragma nounroll
+  for (int phase = FIRST ? 1 : 0; phase < 2; ++phase) {
+    const Walk k = phase == 0 ? pre : main_walk;
+    if (k.repeat <= 0 || k.len <= 0) continue;
+    wk.run(k, P.W);
+    if (phase == 0) {
+      // The forward walk re-reads what the pre-walk just wrote: drain the
+      // stores, then drop this CU's L1 copies of those lines.
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    }
+  }
+}
+
+template <int VPL>
+int launch_family(const float *cost, const float *image, float *out, const SgmShape &P,
+                  bool vec, bool first, hipStream_t s) {
+  const int waves = P.paths * P.batch;
+  const dim3 grid((waves + kSgmBlock / kWave - 1) / (kSgmBlock / kWave)), block(kSgmBlock);
+  if (vec && first)
+    hipLaunchKernelGGL((sgm_pass_kernel<VPL, true, true>), grid, block, 0, s, cost, image, out, P);
+  else if (vec)
+    hipLaunchKernelGGL((sgm_pass_kernel<VPL, true, false>), grid, block, 0, s, cost, image, out, P);
+  else if (first)
+    hipLaunchKernelGGL((sgm_pass_kernel<VPL, false, true>), grid, block, 0, s, cost, image, out, P);
+  else
+    hipLaunchKernelGGL((sgm_pass_kernel<VPL, false, false>), grid, block, 0, s, cost, image, out, P);
+  return check_launch("stm_sgm_f32");
+}
+
+}  // namespace
+}  // namespace stm
+
+extern "C" size_t stm_sgm_workspace_bytes(int H, int W, int D, int batch, int flags) {
+  (void)H; (void)W; (void)D; (void)batch; (void)flags;
+  return 0;  // the path-parallel passes need no scratch
+}
+
+extern "C" int stm_sgm_f32(const float *cost, const float *left, float *out, int H, int W,
+                           int D, float penalty1, float penalty2, int flags, void *workspace,
+                           size_t workspace_bytes, int batch, void *stream) {
+  using namespace stm;
+  (void)workspace; (void)workspace_bytes;
+  STM_REQUIRE(cost && left && out, STM_EINVAL, "stm_sgm_f32: null pointer");
+  STM_REQUIRE(H > 0 && W > 0 && D > 0 && batch > 0, STM_EINVAL,
+              "stm_sgm_f32: non-positive size (H=%d W=%d D=%d batch=%d)", H, W, D, batch);
+  STM_REQUIRE(cost != out, STM_EINVAL, "stm_sgm_f32: cost and out must not alias");
+  STM_REQUIRE(D <= STM_MAX_DISPARITY, STM_EUNSUPPORTED,
+              "stm_sgm_f32: D=%d exceeds %d", D, STM_MAX_DISPARITY);
+  // The reference stores path coordinates as int16 (src/semiglobal.hpp:34-36).
+  STM_REQUIRE(H < 32768 && W < 32768, STM_EUNSUPPORTED,
+              "stm_sgm_f32: image side exceeds the reference's int16 path coordinates");
+  STM_REQUIRE((long long)batch * (W + H) < (1ll << 30), STM_EUNSUPPORTED,
+              "stm_sgm_f32: too many paths in one launch");
+  const int vpl = (D + kWave - 1) / kWave;
+  int VPL = 1;
+  while (VPL < vpl) VPL <<= 1;  // 1, 2, 4, 8, 16
+  const uintptr_t align = VPL >= 4 ? 15 : (VPL == 2 ? 7 : 3);
+  const bool vec = (D == VPL * kWave) &&
+                   ((reinterpret_cast<uintptr_t>(cost) & align) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(out) & align) == 0);
+  hipStream_t s = as_stream(stream);
+  SgmShape P;
+  P.H = H; P.W = W; P.D = D; P.p1 = penalty1; P.p2 = penalty2; P.batch = batch;
+  for (int family = 0; family < 8; ++family) {
+    P.family = family;
+    P.paths = sgm_family_paths(family, H, W);
+    const bool first = family == 0 && !(flags & STM_SGM_ACCUMULATE);
+    int rc;
+    switch (VPL) {
+      case 1: rc = launch_family<1>(cost, left, out, P, vec, first, s); break;
+      case 2: rc = launch_family<2>(cost, left, out, P, vec, first, s); break;
+      case 4: rc = launch_family<4>(cost, left, out, P, vec, first, s); break;
+      case 8: rc = launch_family<8>(cost, left, out, P, vec, first, s); break;
+      default: rc = launch_family<16>(cost, left, out, P, vec, first, s); break;
+    }
+    if (rc != STM_OK) return rc;
+  }
+  return STM_OK;
+}

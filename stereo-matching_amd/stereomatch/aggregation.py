@@ -1,0 +1,55 @@
+"""Cost-volume aggregation (counterpart of upstream ``stereomatch/aggregation.py``)."""
+from typing import Optional
+
+import torch
+
+from . import _native
+from ._common import output_tensor
+
+
+class Semiglobal:
+    """Semiglobal matching aggregation with the gradient-adaptive second penalty.
+
+    ``Semiglobal(penalty1=0.1, penalty2=0.2)`` as upstream ``aggregation.py:26-33``;
+    calls ``stm_sgm_f32`` (reference ``AggregationOps.run_semiglobal``,
+    src/semiglobal.cpp:167-197).  The result equals the reference CPU path bit for bit:
+    eight path directions summed in its path-table order, including its quirks for the
+    inverse diagonals and the minimum over ``d < D-1``.
+
+    The reference zero-fills the output and accumulates into it
+    (``aggregation.py:51``); here the first pass overwrites the output instead, which
+    gives the same values without the extra fill and read.
+    """
+
+    def __init__(self, penalty1: float = 0.1, penalty2: float = 0.2):
+        self.penalty1 = penalty1
+        self.penalty2 = penalty2
+        self._workspace = None
+
+    def __call__(self, cost_volume: torch.Tensor, left_image: torch.Tensor,
+                 sga_volume: Optional[torch.Tensor] = None) -> torch.Tensor:
+        _native.require_gpu(cost_volume, left_image)
+        if cost_volume.dtype != torch.float32:
+            raise RuntimeError("SemiglobalCPU: float32 cost volumes only on this device path")
+        batch, (height, width, max_disparity) = _native.split_batch(cost_volume, 3)
+        if tuple(left_image.shape) != tuple(cost_volume.shape[:-1]):
+            raise RuntimeError("stereomatch: left image shape %s does not match cost volume %s"
+                               % (tuple(left_image.shape), tuple(cost_volume.shape)))
+        device = cost_volume.device
+        if sga_volume is not None and sga_volume.data_ptr() == cost_volume.data_ptr():
+            sga_volume = None  # in-place aggregation is not possible
+        sga_volume = output_tensor(cost_volume.shape, torch.float32, device, reuse=sga_volume)
+        cost = cost_volume.contiguous()
+        image = left_image.float().contiguous()
+        lib = _native.lib()
+        ws_bytes = lib.stm_sgm_workspace_bytes(height, width, max_disparity, batch, 0)
+        if ws_bytes and (self._workspace is None or self._workspace.device != device
+                         or self._workspace.numel() < ws_bytes):
+            self._workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+        ws_ptr = self._workspace.data_ptr() if (ws_bytes and self._workspace is not None) else None
+        with torch.cuda.device(device):
+            _native.check(lib.stm_sgm_f32(
+                cost.data_ptr(), image.data_ptr(), sga_volume.data_ptr(), height, width,
+                max_disparity, float(self.penalty1), float(self.penalty2), 0, ws_ptr, ws_bytes,
+                batch, _native.stream_ptr(device)))
+        return sga_volume

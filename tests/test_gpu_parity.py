@@ -1,0 +1,268 @@
+"""HIP path vs CPU oracle on seeded inputs (bit-exact), through the stereomatch package
+and hence the C ABI.  Mirrors the reference's CPU-vs-GPU equality tests
+(tests/test_cost.py:41-57,135-152, tests/test_semiglobalmatch.py:39-55,
+tests/test_winners_take_all.py:26-48) with the oracle in the CPU role."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32) if a.dtype == np.float32 else a
+
+
+def assert_same_bits(got, want, what=""):
+    got = np.ascontiguousarray(got)
+    want = np.ascontiguousarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    if not np.array_equal(_bits(got), _bits(want)):
+        bad = np.argwhere(_bits(got) != _bits(want))
+        i = tuple(bad[0])
+        raise AssertionError("%s: %d of %d entries differ; first at %s: got %r want %r"
+                             % (what, len(bad), got.size, i, got[i], want[i]))
+
+
+def _gpu(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def _random_volume(rng, H, W, D, kind):
+    if kind == "float":
+        return (rng.random((H, W, D), dtype=np.float32) * 100).astype(np.float32)
+    if kind == "ties":  # few distinct integer values: many exact ties
+        return rng.integers(0, 4, size=(H, W, D)).astype(np.float32)
+    if kind == "inf":
+        v = (rng.random((H, W, D), dtype=np.float32) * 10).astype(np.float32)
+        v[rng.random((H, W, D)) < 0.3] = np.inf
+        v[0, 0, :] = np.inf       # an all-inf pixel must answer 0
+        return v
+    if kind == "last":  # minimum at the last disparity
+        v = (rng.random((H, W, D), dtype=np.float32) * 50 + 10).astype(np.float32)
+        v[..., D - 1] = rng.random((H, W), dtype=np.float32)
+        return v
+    raise ValueError(kind)
+
+
+# ---------------------------------------------------------------- winner takes all
+@pytest.mark.parametrize("H,W,D", [(7, 9, 16), (5, 33, 64), (6, 11, 100), (9, 17, 128),
+                                    (4, 13, 256), (3, 5, 512), (3, 7, 1), (5, 6, 3), (2, 3, 1024)])
+@pytest.mark.parametrize("kind", ["float", "ties", "inf"])
+def test_wta_matches_oracle(device, oracle, H, W, D, kind):
+    import stereomatch
+    rng = np.random.default_rng(H * 1000 + W * 10 + D)
+    vol = _random_volume(rng, H, W, D, kind)
+    got = stereomatch.disparity_reduce.WinnerTakesAll(require_power_of_two=False)(_gpu(vol, device))
+    assert got.dtype == torch.int32
+    assert_same_bits(got.cpu().numpy(), oracle.wta(vol), "wta %s" % kind)
+
+
+def test_wta_nan_rules(device, oracle):
+    import stereomatch
+    rng = np.random.default_rng(5)
+    vol = _random_volume(rng, 6, 8, 64, "float")
+    vol[0, 0, 0] = np.nan      # NaN at d = 0 always wins
+    vol[1, 1, 5] = np.nan      # NaN at d > 0 never wins
+    vol[2, 2, 1:] = np.nan
+    got = stereomatch.disparity_reduce.WinnerTakesAll()(_gpu(vol, device))
+    assert_same_bits(got.cpu().numpy(), oracle.wta(vol), "wta nan")
+
+
+def test_wta_reference_arange_case(device, oracle):
+    """tests/test_winners_take_all.py:26-39 uses an arange volume."""
+    import stereomatch
+    vol = np.arange(60 * 70 * 128, dtype=np.float32).reshape(60, 70, 128)
+    got = stereomatch.disparity_reduce.WinnerTakesAll()(_gpu(vol, device))
+    assert_same_bits(got.cpu().numpy(), oracle.wta(vol), "wta arange")
+
+
+def test_wta_non_power_of_two_raises(device):
+    """tests/test_winners_take_all.py:42-48."""
+    import stereomatch
+    with pytest.raises(RuntimeError):
+        stereomatch.disparity_reduce.WinnerTakesAll()(torch.zeros(30, 30, 100, device=device))
+
+
+# ---------------------------------------------------------------------------- SSD
+SSD_CASES = [(24, 40, 16, 7), (40, 24, 16, 7), (33, 70, 64, 7), (20, 150, 128, 7),
+             (9, 300, 256, 7), (30, 45, 32, 3), (18, 40, 24, 1), (25, 140, 100, 5),
+             (16, 30, 64, 7)]
+
+
+@pytest.mark.parametrize("H,W,D,k", SSD_CASES)
+@pytest.mark.parametrize("kind", ["u8", "unit"])
+@pytest.mark.parametrize("mode", ["ordered", "auto"])
+def test_ssd_matches_oracle(device, oracle, H, W, D, k, kind, mode):
+    import stereomatch
+    L, R = oracle.synthetic_pair(H, W, seed=H + W + D, kind=kind)
+    want = oracle.ssd(L, R, D, k)
+    got = stereomatch.cost.SSD(D, kernel_size=k, mode=mode)(_gpu(L, device), _gpu(R, device))
+    assert_same_bits(got.cpu().numpy(), want, "ssd %s %s" % (kind, mode))
+
+
+@pytest.mark.parametrize("H,W,D,k", SSD_CASES)
+def test_ssd_box_exact_on_integer_images(device, oracle, H, W, D, k):
+    import stereomatch
+    L, R = oracle.synthetic_pair(H, W, seed=3, kind="u8")
+    got = stereomatch.cost.SSD(D, kernel_size=k, mode="box")(_gpu(L, device), _gpu(R, device))
+    assert_same_bits(got.cpu().numpy(), oracle.ssd(L, R, D, k), "ssd box")
+
+
+def test_ssd_rejects_uint8(device):
+    """byte images raise 'SSDKernel: type not supported'."""
+    import stereomatch
+    img = torch.zeros(8, 8, dtype=torch.uint8, device=device)
+    with pytest.raises(RuntimeError, match="type not supported"):
+        stereomatch.cost.SSD(8)(img, img)
+
+
+# --------------------------------------------------------------------- Birchfield
+@pytest.mark.parametrize("H,W,D", [(24, 40, 16), (40, 24, 16), (12, 130, 64), (7, 200, 128),
+                                    (5, 70, 256), (9, 50, 20)])
+@pytest.mark.parametrize("kind", ["u8", "unit"])
+def test_birchfield_matches_oracle(device, oracle, H, W, D, kind):
+    import stereomatch
+    L, R = oracle.synthetic_pair(H, W, seed=11 + D, kind=kind)
+    got = stereomatch.cost.Birchfield(D)(_gpu(L, device), _gpu(R, device))
+    assert_same_bits(got.cpu().numpy(), oracle.birchfield(L, R, D), "birchfield " + kind)
+
+
+def test_birchfield_leaves_upper_entries_untouched(device, oracle):
+    import stereomatch
+    L, R = oracle.synthetic_pair(10, 30, seed=1)
+    buf = torch.full((10, 30, 16), 123.0, device=device)
+    out = stereomatch.cost.Birchfield(16)(_gpu(L, device), _gpu(R, device), cost_volume=buf)
+    assert out is buf
+    want = oracle.birchfield(L, R, 16, out=np.full((10, 30, 16), 123.0, dtype=np.float32))
+    assert_same_bits(out.cpu().numpy(), want, "birchfield reuse")
+
+
+# ---------------------------------------------------------------------------- SGM
+SGM_CASES = [(24, 40, 16), (40, 24, 16), (20, 20, 16), (21, 20, 8), (20, 22, 64), (11, 37, 64),
+             (37, 11, 64), (13, 30, 128), (30, 13, 128), (9, 21, 256), (8, 12, 512),
+             (10, 14, 100), (7, 9, 2), (6, 8, 1), (1, 9, 16), (9, 1, 16), (2, 2, 64)]
+
+
+@pytest.mark.parametrize("H,W,D", SGM_CASES)
+def test_sgm_on_ssd_volume_matches_oracle(device, oracle, H, W, D):
+    import stereomatch
+    L, R = oracle.synthetic_pair(H, W, seed=D + H)
+    C = oracle.ssd(L, R, D, 3)
+    want = oracle.sgm(C, L, 0.1, 0.2)
+    got = stereomatch.aggregation.Semiglobal(0.1, 0.2)(_gpu(C, device), _gpu(L, device))
+    assert_same_bits(got.cpu().numpy(), want, "sgm ssd-volume")
+
+
+@pytest.mark.parametrize("H,W,D", SGM_CASES[:12])
+@pytest.mark.parametrize("kind", ["float", "ties", "last"])
+def test_sgm_on_random_volume_matches_oracle(device, oracle, H, W, D, kind):
+    import stereomatch
+    rng = np.random.default_rng(17 * H + W + D)
+    C = _random_volume(rng, H, W, D, kind)
+    image = rng.integers(0, 5, size=(H, W)).astype(np.float32)   # many zero gradients
+    want = oracle.sgm(C, image, 0.5, 3.0)
+    got = stereomatch.aggregation.Semiglobal(0.5, 3.0)(_gpu(C, device), _gpu(image, device))
+    assert_same_bits(got.cpu().numpy(), want, "sgm " + kind)
+
+
+def test_sgm_reference_ones_arange_case(device, oracle):
+    """tests/test_semiglobalmatch.py:39-55: ones image, arange volume."""
+    import stereomatch
+    H = W = 60
+    image = np.ones((H, W), dtype=np.float32)
+    C = np.arange(H * W * 128, dtype=np.float32).reshape(H, W, 128)
+    got = stereomatch.aggregation.Semiglobal()(_gpu(C, device), _gpu(image, device))
+    assert_same_bits(got.cpu().numpy(), oracle.sgm(C, image), "sgm ones/arange")
+
+
+def test_sgm_reuses_output_buffer(device, oracle):
+    import stereomatch
+    L, R = oracle.synthetic_pair(16, 20, seed=2)
+    C = oracle.ssd(L, R, 16, 3)
+    sgm = stereomatch.aggregation.Semiglobal()
+    buf = torch.full((16, 20, 16), 7.0, device=device)
+    out = sgm(_gpu(C, device), _gpu(L, device), buf)
+    assert out is buf
+    assert_same_bits(out.cpu().numpy(), oracle.sgm(C, L), "sgm reuse")
+
+
+# ----------------------------------------------------------------------------- DP
+DP_CASES = [(20, 30, 16), (24, 40, 16), (64, 64, 64), (16, 16, 16), (130, 140, 128),
+            (70, 90, 40), (8, 300, 4), (5, 9, 1), (260, 270, 256)]
+
+
+@pytest.mark.parametrize("H,W,D", DP_CASES)
+@pytest.mark.parametrize("kind", ["float", "ties", "inf"])
+def test_dp_reference_mode_matches_oracle(device, oracle, H, W, D, kind):
+    import stereomatch
+    rng = np.random.default_rng(H + 3 * W + D)
+    vol = _random_volume(rng, H, W, D, kind)
+    want, wpath, wfinal = oracle.dp(vol, mode=0, return_aux=True)
+    dp = stereomatch.disparity_reduce.DynamicProgramming()
+    got = dp(_gpu(vol, device))
+    assert_same_bits(dp.row_final_costs.cpu().numpy(), wfinal, "dp row_final")
+    assert_same_bits(dp.path_volume.cpu().numpy(), wpath, "dp path")
+    assert_same_bits(got.cpu().numpy(), want, "dp disparity")
+
+
+@pytest.mark.parametrize("H,W,D", [(10, 7, 16), (5, 40, 64), (30, 12, 128), (3, 2, 8)])
+def test_dp_corrected_mode_matches_oracle(device, oracle, H, W, D):
+    import stereomatch
+    rng = np.random.default_rng(H * W + D)
+    vol = _random_volume(rng, H, W, D, "float")
+    want, wpath, wfinal = oracle.dp(vol, mode=1, return_aux=True)
+    dp = stereomatch.disparity_reduce.DynamicProgramming(mode="corrected")
+    got = dp(_gpu(vol, device))
+    assert_same_bits(dp.path_volume.cpu().numpy(), wpath, "dp path")
+    assert_same_bits(got.cpu().numpy(), want, "dp corrected")
+
+
+def test_dp_reference_mode_needs_D_le_H_le_W(device):
+    import stereomatch
+    with pytest.raises(RuntimeError, match="D <= H <= W"):
+        stereomatch.disparity_reduce.DynamicProgramming()(torch.zeros(8, 4, 16, device=device))
+
+
+def test_dp_after_sgm_long_chains(device, oracle):
+    """Smooth volumes make the in-place chain long; the fixed-point iteration must still
+    reproduce it."""
+    import stereomatch
+    H, W, D = 70, 80, 64
+    d = np.arange(D, dtype=np.float32)
+    vol = np.broadcast_to(0.001 * d, (H, W, D)).astype(np.float32).copy()
+    vol += np.random.default_rng(0).random((H, W, 1), dtype=np.float32)
+    want, wpath, _ = oracle.dp(vol, mode=0, return_aux=True)
+    dp = stereomatch.disparity_reduce.DynamicProgramming()
+    got = dp(_gpu(vol, device))
+    assert_same_bits(dp.path_volume.cpu().numpy(), wpath, "dp path (chains)")
+    assert_same_bits(got.cpu().numpy(), want, "dp chains")
+
+
+# ------------------------------------------------------------------------ batching
+def test_batched_calls_equal_per_pair_calls(device, oracle):
+    import stereomatch
+    H, W, D, B = 18, 26, 64, 3
+    pairs = [oracle.synthetic_pair(H, W, seed=s) for s in range(B)]
+    L = _gpu(np.stack([p[0] for p in pairs]), device)
+    R = _gpu(np.stack([p[1] for p in pairs]), device)
+    ssd = stereomatch.cost.SSD(D, kernel_size=3)
+    sgm = stereomatch.aggregation.Semiglobal()
+    wta = stereomatch.disparity_reduce.WinnerTakesAll()
+    dp = stereomatch.disparity_reduce.DynamicProgramming(mode="corrected")
+    bt = stereomatch.cost.Birchfield(D)
+    C = ssd(L, R)
+    S = sgm(C, L)
+    disp = wta(S)
+    dpd = dp(S)
+    B_ = bt(L, R)
+    for b in range(B):
+        Cb = oracle.ssd(pairs[b][0], pairs[b][1], D, 3)
+        Sb = oracle.sgm(Cb, pairs[b][0])
+        assert_same_bits(C[b].cpu().numpy(), Cb, "batched ssd")
+        assert_same_bits(S[b].cpu().numpy(), Sb, "batched sgm")
+        assert_same_bits(disp[b].cpu().numpy(), oracle.wta(Sb), "batched wta")
+        assert_same_bits(dpd[b].cpu().numpy(), oracle.dp(Sb, mode=1), "batched dp")
+        assert_same_bits(B_[b].cpu().numpy(), oracle.birchfield(pairs[b][0], pairs[b][1], D),
+                         "batched birchfield")
