@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""Benchmark of the stereo cost-volume hot path on MI355X.
+
+One *step* = SSD cost fill -> 8-path semiglobal aggregation -> winner-takes-all over one
+batch of synthetic stereo pairs that is already resident in HBM (through the
+``stereomatch`` package, i.e. the C ABI of libstereomatch_hip.so).  The metric is
+BASELINE.json's: stereo pairs per second, whole job.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workloads (BASELINE.json ``configs``):
+  teddy  = configs[1]: 375x450, SSD(128, k=7) + SGM(0.1, 0.2) + WTA      (primary, `value`)
+  1080p  = configs[3]: 1080x1920, SSD(256) + SGM + WTA                    (reported under
+           "also", with its own roofline: the HBM-roofline configuration)
+Multi-GPU: independent pairs are sharded over ranks (weak scaling: every rank runs the
+same batch size); the only collective is the final all_gather of the int32 disparity
+maps over RCCL, inside the timed step.
+
+Rank 0 prints ONE JSON line.  ``roofline`` is for the semiglobal aggregation (the
+dominant kernel family, eight launches of sgm_pass_kernel per step): achieved =
+8 bytes x H*W*D x pairs  /  time of the eight launches, measured with HIP events on the
+launch stream inside the timed region.  ``cpu_baseline`` times the CPU oracle (1 thread,
+the reference as shipped) on a bounded sample of the primary workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "stereo-matching_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+WORKLOADS = {
+    # name: (H, W, D, default pairs per GPU per step, digest of pair 0's disparity map)
+    # digests: SURVEY.md Appendix C, SSD+SGM+WTA on the seed-0 pair (reference CPU output).
+    "teddy": dict(H=375, W=450, D=128, batch=16, digest="9693be8fb6aa9b99",
+                  config="Teddy 450x375, SSD + 8-path SGM + WTA, D=128"),
+    "1080p": dict(H=1080, W=1920, D=256, batch=2, digest=None,
+                  config="1920x1080 synthetic pair, SSD + SGM + WTA, D=256"),
+}
+
+
+def synthetic_pair(H, W, seed, shift=7):
+    """integer-valued 0..255 float32 images, constant true disparity 7."""
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, size=(H, W + 64)).astype(np.float32)
+    return (np.ascontiguousarray(base[:, 32:32 + W]),
+            np.ascontiguousarray(base[:, 32 + shift:32 + shift + W]))
+
+
+def digest16(t):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(t).tobytes()).hexdigest()[:16]
+
+
+class Job:
+    """Buffers and ops of one workload on one GPU."""
+
+    def __init__(self, name, batch, rank, device):
+        import stereomatch
+        w = WORKLOADS[name]
+        self.name, self.w, self.batch, self.device = name, w, batch, device
+        H, W, D = w["H"], w["W"], w["D"]
+        pairs = [synthetic_pair(H, W, seed=rank * batch + b) for b in range(batch)]
+        self.left = torch.from_numpy(np.stack([p[0] for p in pairs])).to(device)
+        self.right = torch.from_numpy(np.stack([p[1] for p in pairs])).to(device)
+        self.ssd = stereomatch.cost.SSD(D, kernel_size=7)
+        self.sgm = stereomatch.aggregation.Semiglobal(0.1, 0.2)
+        self.wta = stereomatch.disparity_reduce.WinnerTakesAll()
+        self.cost = self.agg = self.disp = None
+        self.gathered = None
+        self.n_elems = H * W * D
+
+    def step(self, events=None, world=1):
+        ev = events
+        if ev is not None:
+            ev[0].record()
+        self.cost = self.ssd(self.left, self.right, cost_volume=self.cost)
+        if ev is not None:
+            ev[1].record()
+        self.agg = self.sgm(self.cost, self.left, self.agg)
+        if ev is not None:
+            ev[2].record()
+        self.disp = self.wta(self.agg, self.disp)
+        if ev is not None:
+            ev[3].record()
+        if world > 1:
+            import torch.distributed as dist
+            if self.gathered is None:
+                self.gathered = torch.empty((world,) + tuple(self.disp.shape), dtype=torch.int32,
+                                            device=self.device)
+            dist.all_gather_into_tensor(self.gathered, self.disp)
+        return self.disp
+
+
+def timed_run(job, steps, warmup, world):
+    import torch.distributed as dist
+    for _ in range(warmup):
+        job.step(world=world)
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        job.step(events[k], world=world)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=job.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    stage_ms = [float(np.mean([e[i].elapsed_time(e[i + 1]) for e in events])) for i in range(3)]
+    return elapsed, stage_ms
+
+
+def roofline(job, sgm_ms, traffic=None):
+    algorithmic = 8.0 * job.n_elems * job.batch  # read cost once + write sum once
+    achieved = algorithmic / (sgm_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "sgm_pass_kernel (8 launches = one aggregation)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "algorithmic_bytes": algorithmic, "ms": round(sgm_ms, 4)}
+
+
+def load_traffic(name):
+    """HBM bytes per aggregation from the committed PMC summary, if there is one."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(name)
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline(budget_s=20.0):
+    """The CPU oracle (bit-exact restatement of the reference CPU path), one thread, on
+    Teddy-sized pairs of the primary workload until ~budget_s seconds are spent."""
+    import oracle
+    oracle.build()
+    w = WORKLOADS["teddy"]
+    done, t0 = 0, time.perf_counter()
+    stages = [0.0, 0.0, 0.0]
+    while True:
+        L, R = synthetic_pair(w["H"], w["W"], seed=done)
+        a = time.perf_counter()
+        C = oracle.ssd(L, R, w["D"], 7)
+        b = time.perf_counter()
+        S = oracle.sgm(C, L, 0.1, 0.2)
+        c = time.perf_counter()
+        disp = oracle.wta(S)
+        d = time.perf_counter()
+        stages[0] += b - a
+        stages[1] += c - b
+        stages[2] += d - c
+        if done == 0:
+            assert digest16(disp) == w["digest"], "oracle digest mismatch"
+        done += 1
+        if time.perf_counter() - t0 > budget_s * 0.75:
+            break
+    total = time.perf_counter() - t0
+    return {"value": round(done / total, 4), "unit": "pairs/s", "cores": 1, "kind": "port",
+            "sample": "%d Teddy-sized pairs (375x450, D=128), oracle SSD+SGM+WTA, 1 thread of %d "
+                      "host cores; per pair: SSD %.2f s, SGM %.2f s, WTA %.3f s"
+                      % (done, os.cpu_count() or 0, stages[0] / done, stages[1] / done,
+                         stages[2] / done)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="teddy", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="pairs per GPU per step (0 = default)")
+    ap.add_argument("--also", default="1080p", help="second workload reported under 'also' ('' = none)")
+    ap.add_argument("--also-steps", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=device)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+
+    from stereomatch import _native
+    _native.lib()  # no HIP library -> fail loudly, there is no fallback
+
+    name = args.workload
+    batch = args.batch or WORKLOADS[name]["batch"]
+    job = Job(name, batch, rank, device)
+    # Parity gate before any timing: pair 0 must reproduce the reference's disparity map.
+    disp = job.step(world=1)
+    torch.cuda.synchronize()
+    if rank == 0 and WORKLOADS[name]["digest"]:
+        got = digest16(disp[0].cpu().numpy())
+        assert got == WORKLOADS[name]["digest"], "parity gate failed: %s" % got
+    elapsed, stage_ms = timed_run(job, args.steps, args.warmup, world)
+    pairs = batch * world * args.steps
+    value = pairs / elapsed
+    w = WORKLOADS[name]
+    out = {
+        "metric": "stereo pairs/sec (SSD+SGM+WTA)", "value": round(value, 2), "unit": "pairs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": w["config"], "H": w["H"], "W": w["W"], "D": w["D"],
+                   "pairs_per_gpu_per_step": batch, "ssd_mode": "auto", "kernel_size": 7,
+                   "penalties": [0.1, 0.2], "sharding": "pairs over ranks, all_gather of disparity maps"},
+        "stage_ms": {"ssd": round(stage_ms[0], 4), "sgm": round(stage_ms[1], 4),
+                     "wta": round(stage_ms[2], 4)},
+        "roofline": roofline(job, stage_ms[1], load_traffic(name)),
+    }
+    del job
+    torch.cuda.empty_cache()
+
+    if args.also and args.also != name and world == 1:
+        w2 = WORKLOADS[args.also]
+        job2 = Job(args.also, w2["batch"], rank, device)
+        e2, s2 = timed_run(job2, args.also_steps, 1, 1)
+        d7 = float((job2.disp == 7).float().mean())
+        out["also"] = {
+            "workload": w2["config"], "value": round(w2["batch"] * args.also_steps / e2, 3),
+            "unit": "pairs/s", "pairs_per_step": w2["batch"], "steps": args.also_steps,
+            "ms_per_step": round(e2 / args.also_steps * 1e3, 3),
+            "stage_ms": {"ssd": round(s2[0], 4), "sgm": round(s2[1], 4), "wta": round(s2[2], 4)},
+            "roofline": roofline(job2, s2[1], load_traffic(args.also)),
+            "pixels_at_true_disparity": round(d7, 4),
+        }
+        del job2
+        torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

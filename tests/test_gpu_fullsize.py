@@ -1,0 +1,114 @@
+"""Full-size parity on the GPU: Teddy-sized runs against the reference-output digests of
+SURVEY.md Appendix C (committed in tests/golden/digests.json) and 1080p runs against
+sampled / full oracle results."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "digests.json")) as f:
+    GOLDEN = json.load(f)
+
+
+def digest16(t):
+    if isinstance(t, torch.Tensor):
+        t = t.cpu().numpy()
+    return hashlib.sha256(np.ascontiguousarray(t).tobytes()).hexdigest()[:16]
+
+
+def _pair(oracle, H, W, device, seed=0):
+    L, R = oracle.synthetic_pair(H, W, seed=seed)
+    return L, R, torch.from_numpy(L).to(device), torch.from_numpy(R).to(device)
+
+
+@pytest.mark.parametrize("case", ["tiny-wide 24x40x16", "tiny-tall 40x24x16",
+                                  "teddy 375x450x64", "teddy 375x450x128"])
+@pytest.mark.parametrize("mode", ["auto", "ordered"])
+def test_pipeline_reproduces_reference_digests(device, oracle, case, mode):
+    """Config 1/2: Pipeline(SSD(D), WTA[, SGM]) on the seed-0 pair, twice (buffer reuse)."""
+    import stereomatch
+    g = GOLDEN[case]
+    H, W, D = g["H"], g["W"], g["D"]
+    L, R, Lg, Rg = _pair(oracle, H, W, device)
+    assert digest16(L) == g["L"] and digest16(R) == g["R"]
+    plain = stereomatch.Pipeline(stereomatch.cost.SSD(D, mode=mode),
+                                 stereomatch.disparity_reduce.WinnerTakesAll())
+    full = stereomatch.Pipeline(stereomatch.cost.SSD(D, mode=mode),
+                                stereomatch.disparity_reduce.WinnerTakesAll(),
+                                stereomatch.aggregation.Semiglobal())
+    for attempt in range(2):
+        d1 = plain.estimate(Lg, Rg)
+        assert digest16(plain._cost_volume) == g["ssd"], "SSD volume (attempt %d)" % attempt
+        assert digest16(d1) == g["ssd_wta"]
+        d2 = full.estimate(Lg, Rg)
+        assert digest16(full._aggregation_volume) == g["sgm"], "SGM volume (attempt %d)" % attempt
+        assert digest16(d2) == g["ssd_sgm_wta"]
+        if attempt == 0:
+            ids = (plain._cost_volume.data_ptr(), d1.data_ptr(), full._aggregation_volume.data_ptr())
+        else:  # second call reuses the first call's buffers
+            assert ids == (plain._cost_volume.data_ptr(), d1.data_ptr(),
+                           full._aggregation_volume.data_ptr())
+
+
+def test_config3_birchfield_sgm_dp_digests(device, oracle):
+    """Config 3 in its pinned form: Birchfield(128) -> SGM -> DP."""
+    import stereomatch
+    g = GOLDEN["config3 375x450x128"]
+    L, R, Lg, Rg = _pair(oracle, g["H"], g["W"], device)
+    pipe = stereomatch.Pipeline(stereomatch.cost.Birchfield(g["D"]),
+                                stereomatch.disparity_reduce.DynamicProgramming(),
+                                stereomatch.aggregation.Semiglobal())
+    disp = pipe.estimate(Lg, Rg)
+    assert digest16(pipe._cost_volume) == g["birchfield"]
+    assert digest16(pipe._aggregation_volume) == g["sgm"]
+    assert digest16(disp) == g["dp"]
+    assert abs(float((disp == 7).float().mean()) - 0.992) < 0.002
+
+
+def test_1080p_ssd_sampled_and_wta_full(device, oracle):
+    """Config 4 stages with local support: SSD checked on 20k sampled entries (both
+    modes agree everywhere), WTA checked on every pixel."""
+    import stereomatch
+    H, W, D = 1080, 1920, 256
+    L, R, Lg, Rg = _pair(oracle, H, W, device)
+    C_auto = stereomatch.cost.SSD(D, mode="auto")(Lg, Rg)
+    C_ord = stereomatch.cost.SSD(D, mode="ordered")(Lg, Rg)
+    assert torch.equal(C_auto.view(torch.int32), C_ord.view(torch.int32))
+    rng = np.random.default_rng(0)
+    n = 20000
+    rows = rng.integers(0, H, n)
+    cols = rng.integers(0, W, n)
+    disps = rng.integers(0, D, n)
+    rows[:200] = rng.integers(0, 8, 200)          # top border
+    rows[200:400] = rng.integers(H - 8, H, 200)   # bottom border
+    cols[400:800] = rng.integers(0, 300, 400)     # left clip / +inf region
+    cols[800:1000] = rng.integers(W - 8, W, 200)  # right border
+    want = oracle.ssd_entries(L, R, 7, rows, cols, disps)
+    got = C_auto[torch.from_numpy(rows).to(device), torch.from_numpy(cols).to(device),
+                 torch.from_numpy(disps).to(device)].cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    disp = stereomatch.disparity_reduce.WinnerTakesAll()(C_auto)
+    assert np.array_equal(disp.cpu().numpy(), oracle.wta(C_auto.cpu().numpy()))
+
+
+def test_1080p_sgm_full_volume_matches_oracle(device, oracle):
+    """Config 4 aggregation, every element: the oracle takes ~15 s on one core."""
+    import stereomatch
+    H, W, D = 1080, 1920, 256
+    L, R, Lg, Rg = _pair(oracle, H, W, device)
+    C = stereomatch.cost.SSD(D)(Lg, Rg)
+    S = stereomatch.aggregation.Semiglobal()(C, Lg)
+    disp = stereomatch.disparity_reduce.WinnerTakesAll()(S)
+    Ch = C.cpu().numpy()
+    del C
+    want = oracle.sgm(Ch, L, 0.1, 0.2)
+    got = S.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(disp.cpu().numpy(), oracle.wta(want))
+    assert float((disp == 7).float().mean()) > 0.9
