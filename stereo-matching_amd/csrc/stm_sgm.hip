@@ -55,77 +55,94 @@ enum Family : int {
 
 struct Walk {
   int x0, y0, dx, dy, len;
-  int repeat;  // how many times each L is added (0 = the reference never runs this pass)
+  int add;    // 1: out += L along this walk; 0: the reference never runs this pass on `out`
+  int spill;  // 1: L rows are also written to the workspace (re-walked diagonal, Q6)
 };
+
+// The reference's mis-stored diagonal end points make some inverse
+// passes re-walk one corner diagonal instead of their own:
+//   W > H : the inverses of group-3 paths i in [H, W-1] all start at (W-1, H-1) and
+//           those of group-5 paths i in [H, W-1] at (0, H-1); each of the two diagonals
+//           therefore receives its L (W-H+1) times, the extra W-H right after its own pass.
+//   H > W+1: the inverses of group-4 paths i in [0, H-W-2] start at (W-1, H-1) and re-walk
+//           the diagonal of path i = H-W-1 (H-W-1 times) BEFORE that path's forward pass.
+// L is the same on every re-walk, so it is computed once, spilled to the workspace, and a
+// pixel-parallel kernel (sgm_repeat_kernel) applies the repeated adds in order.
+struct SgmQuirk {
+  int wide_extra;  // W - H  when W > H, else 0
+  int tall_extra;  // H-W-1 when H > W+1, else 0
+};
+__host__ __device__ inline SgmQuirk sgm_quirk(int H, int W) {
+  SgmQuirk q;
+  q.wide_extra = W > H ? W - H : 0;
+  q.tall_extra = H > W + 1 ? H - W - 1 : 0;
+  return q;
+}
 
 __host__ __device__ inline int sgm_family_paths(int family, int H, int W) {
   switch (family) {
     case kRight: case kLeft: return H;
-    case kDown: case kUp: return W;
+    case kDown: return W;
+    // One extra wave walks the tall-image corner diagonal (compute + spill only) while
+    // the vertical inverses run; its repeated adds land between families kUp and kDownRight.
+    case kUp: return W + (sgm_quirk(H, W).tall_extra > 0 ? 1 : 0);
     default: return W + H - 1;
   }
 }
 
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 
-// Start, direction, length and repeat count of path `w` of a family, following
-// GeneratePaths and SGPixelPath::inverse() (src/semiglobal.hpp:42-45) entry by
-// entry.  `pre` receives the walk that has to run *before* this one on the same
-// wave (tall images only, see below).
-__device__ __forceinline__ Walk sgm_decode(int family, int w, int H, int W, Walk *pre) {
+// Start, direction and length of path `w` of a family, following GeneratePaths and
+// SGPixelPath::inverse() (src/semiglobal.hpp:42-45) entry by entry.
+__device__ __forceinline__ Walk sgm_decode(int family, int w, int H, int W) {
   Walk k;
-  k.repeat = 1;
-  pre->repeat = 0;
   switch (family) {
-    case kRight: k = {0, w, 1, 0, W, 1}; break;
-    case kLeft: k = {W - 1, w, -1, 0, W, 1}; break;
-    case kDown: k = {w, 0, 0, 1, H, 1}; break;
-    case kUp: k = {w, H - 1, 0, -1, H, 1}; break;
+    case kRight: k = {0, w, 1, 0, W, 1, 0}; break;
+    case kLeft: k = {W - 1, w, -1, 0, W, 1, 0}; break;
+    case kDown: k = {w, 0, 0, 1, H, 1, 0}; break;
+    case kUp:
+      if (w < W) k = {w, H - 1, 0, -1, H, 1, 0};
+      else k = {W - 1, H - 1, -1, -1, W, 0, 1};  // tall corner diagonal, spill only
+      break;
     case kDownRight:
       if (w < W) {  // semiglobal.cpp:45-50
-        k = {W - 1 - w, 0, 1, 1, imin(w, H - 1) + 1, 1};
+        k = {W - 1 - w, 0, 1, 1, imin(w, H - 1) + 1, 1, 0};
       } else {      // :52-61
         const int i = w - W;
-        k = {0, i + 1, 1, 1, imin(H - 2 - i, W - 1) + 1, 1};
-        // Tall images: the inverses of paths i < H-W-1 of this group start at the
-        // wrong stored end (W-1, H-1) and so re-walk the diagonal that belongs to
-        // path i = H-W-1, *before* that path's own forward pass in table order.
-        if (H > W + 1 && i == H - W - 1) *pre = {W - 1, H - 1, -1, -1, W, H - W - 1};
+        k = {0, i + 1, 1, 1, imin(H - 2 - i, W - 1) + 1, 1, 0};
       }
       break;
     case kUpLeft:
       if (w < W) {
         const int ey = imin(w, H - 1);
-        k = {W - 1, ey, -1, -1, ey + 1, 1};
-        // Wide images: for w >= H the stored end is (W-1, H-1) instead of the true
-        // end, so those passes all re-walk the diagonal of path w = H-1.
-        if (w >= H) k.repeat = 0;
-        else if (w == H - 1 && W > H) k.repeat = W - H + 1;
+        k = {W - 1, ey, -1, -1, ey + 1, 1, 0};
+        if (w >= H) k.add = 0;                      // duplicate of w = H-1 (wide)
+        else if (w == H - 1 && W > H) k.spill = 1;  // the re-walked diagonal itself
       } else {
         const int i = w - W;
         const int ex = imin(H - 2 - i, W - 1);
-        k = {ex, H - 1, -1, -1, ex + 1, 1};
-        if (W - 1 < H - 2 - i) k.repeat = 0;  // re-walks handled by the `pre` walk above
+        k = {ex, H - 1, -1, -1, ex + 1, 1, 0};
+        if (W - 1 < H - 2 - i) k.add = 0;           // duplicate of i = H-W-1 (tall)
       }
       break;
     case kDownLeft:
       if (w < W) {  // :66-74
-        k = {w, 0, -1, 1, imin(w + 1, H), 1};
+        k = {w, 0, -1, 1, imin(w + 1, H), 1, 0};
       } else {      // :76-89
         const int i = w - W;
-        k = {W - 1, i + 1, -1, 1, imin(H - (i + 1), W), 1};
+        k = {W - 1, i + 1, -1, 1, imin(H - (i + 1), W), 1, 0};
       }
       break;
     default:  // kUpRight
       if (w < W) {
         const int len = imin(w + 1, H);
-        k = {0, len - 1, 1, -1, len, 1};
-        if (w >= H) k.repeat = 0;  // stored end (0, H-1) is wrong: duplicates of w = H-1
-        else if (w == H - 1 && W > H) k.repeat = W - H + 1;
+        k = {0, len - 1, 1, -1, len, 1, 0};
+        if (w >= H) k.add = 0;                      // stored end (0, H-1): duplicate of w = H-1
+        else if (w == H - 1 && W > H) k.spill = 1;
       } else {
         const int i = w - W;
         const int len = imin(H - (i + 1), W);
-        k = {W - len, i + len, 1, -1, len, 1};
+        k = {W - len, i + len, 1, -1, len, 1, 0};
       }
       break;
   }
@@ -140,6 +157,7 @@ struct Walker {
   const float *__restrict__ cost;
   const float *__restrict__ image;
   float *__restrict__ out;
+  float *__restrict__ spill;  // workspace rows of this image, or nullptr
   int D, d0;
   float p1, p2;
   Row<VPL> prev;
@@ -181,16 +199,15 @@ struct Walker {
     return cur;
   }
 
-  __device__ __forceinline__ void emit(long q, const Row<VPL> &s, const Row<VPL> &cur,
-                                       int repeat) const {
-    Row<VPL> o;
+  __device__ __forceinline__ void emit(long q, int i, const Row<VPL> &s, const Row<VPL> &cur,
+                                       const Walk &k) const {
+    if (k.add) {
+      Row<VPL> o;
 #pragma unroll
-    for (int j = 0; j < VPL; ++j) o.v[j] = (FIRST ? 0.0f : s.v[j]) + cur.v[j];
-    for (int r = 1; r < repeat; ++r) {  // re-walked diagonals only (Q6)
-#pragma unroll
-      for (int j = 0; j < VPL; ++j) o.v[j] = o.v[j] + cur.v[j];
+      for (int j = 0; j < VPL; ++j) o.v[j] = (FIRST ? 0.0f : s.v[j]) + cur.v[j];
+      store_row<VPL, VEC>(out, (size_t)q, D, d0, o);
     }
-    store_row<VPL, VEC>(out, (size_t)q, D, d0, o);
+    if (k.spill) store_row<VPL, VEC>(spill, (size_t)i, D, d0, cur);
   }
 
   __device__ __forceinline__ void run(const Walk k, int W) {
@@ -211,7 +228,7 @@ struct Walker {
       const Row<VPL> s = sbuf[0];
       prev_i = ibuf[0];
       fetch(pix + (long)imin(kPF, last) * step, cbuf[0], sbuf[0], ibuf[0]);
-      emit(pix, s, c, k.repeat);
+      emit(pix, 0, s, c, k);
       prev = c;
       pix += step;
     }
@@ -225,7 +242,7 @@ struct Walker {
         const float inten = ibuf[u];
         fetch(pix + (long)imin(kPF, last - i) * step, cbuf[u], sbuf[u], ibuf[u]);
         const Row<VPL> cur = advance(c, inten);
-        emit(pix, s, cur, k.repeat);
+        emit(pix, i, s, cur, k);
         prev = cur;
         prev_i = inten;
         pix += step;
@@ -241,7 +258,7 @@ struct Walker {
         const float inten = ibuf[u];
         fetch(pix + (long)imin(kPF, last - (i + u)) * step, cbuf[u], sbuf[u], ibuf[u]);
         const Row<VPL> cur = advance(c, inten);
-        emit(pix, s, cur, k.repeat);
+        emit(pix, i + u, s, cur, k);
         prev = cur;
         prev_i = inten;
         pix += step;
@@ -252,7 +269,7 @@ struct Walker {
     for (int u = 0; u < kPF - 1; ++u) {
       if (i < k.len) {
         const Row<VPL> cur = advance(cbuf[u], ibuf[u]);
-        emit(pix, sbuf[u], cur, k.repeat);
+        emit(pix, i, sbuf[u], cur, k);
         prev = cur;
         prev_i = ibuf[u];
         pix += step;
@@ -266,14 +283,16 @@ struct SgmShape {
   int H, W, D;
   float p1, p2;
   int family;
-  int paths;  // paths per image in this family
+  int paths;     // waves per image in this family (sgm_family_paths)
   int batch;
+  int ws_rows;   // workspace rows per image (min(H, W)), 0 when there is no workspace
 };
 
 template <int VPL, bool VEC, bool FIRST>
 __global__ __launch_bounds__(kSgmBlock) void sgm_pass_kernel(const float *__restrict__ cost_all,
                                                              const float *__restrict__ image_all,
                                                              float *__restrict__ out_all,
+                                                             float *__restrict__ ws_all,
                                                              const SgmShape P) {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = wave_uniform((int)(blockIdx.x * (kSgmBlock / kWave) + (threadIdx.x >> 6)));
@@ -286,55 +305,86 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pass_kernel(const float *__rest
   wk.cost = cost_all + (size_t)b * npix * P.D;
   wk.image = image_all + (size_t)b * npix;
   wk.out = out_all + (size_t)b * npix * P.D;
+  wk.spill = ws_all ? ws_all + (size_t)b * P.ws_rows * P.D : nullptr;
   wk.D = P.D;
   wk.d0 = lane * VPL;
   wk.p1 = P.p1;
   wk.p2 = P.p2;
 
-  Walk pre;
-  const Walk main_walk = sgm_decode(P.family, w, P.H, P.W, &pre);
-#pragma nounroll
-  for (int phase = FIRST ? 1 : 0; phase < 2; ++phase) {
-    const Walk k = phase == 0 ? pre : main_walk;
-    if (k.repeat <= 0 || k.len <= 0) continue;
-    wk.run(k, P.W);
-    if (phase == 0) {
-      // The forward walk re-reads what the pre-walk just wrote: drain the
-      // stores, then drop this CU's L1 copies of those lines.
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-    }
-  }
+  Walk k = sgm_decode(P.family, w, P.H, P.W);
+  if (!wk.spill) k.spill = 0;
+  if ((k.add | k.spill) && k.len > 0) wk.run(k, P.W);
+}
+
+// Repeated adds of a spilled diagonal: out(p_i, d) = (...((out + L_i) + L_i)...) `count`
+// times, one thread per (pixel of the walk, disparity); the chain per element is
+// sequential, elements are independent.
+struct SgmRepeat {
+  int H, W, D, batch, ws_rows;
+  int x0, y0, dx, dy, len, count;
+};
+__global__ __launch_bounds__(256) void sgm_repeat_kernel(float *__restrict__ out_all,
+                                                         const float *__restrict__ ws_all,
+                                                         const SgmRepeat R) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (idx >= (long)R.len * R.D) return;
+  const int i = (int)(idx / R.D);
+  const int d = (int)(idx - (long)i * R.D);
+  const long pix = (long)(R.y0 + i * R.dy) * R.W + (R.x0 + i * R.dx);
+  float *o = out_all + ((size_t)b * R.H * R.W + (size_t)pix) * R.D + d;
+  const float l = ws_all[((size_t)b * R.ws_rows + i) * R.D + d];
+  float acc = *o;
+  for (int r = 0; r < R.count; ++r) acc = acc + l;
+  *o = acc;
 }
 
 template <int VPL>
-int launch_family(const float *cost, const float *image, float *out, const SgmShape &P,
-                  bool vec, bool first, hipStream_t s) {
+int launch_family(const float *cost, const float *image, float *out, float *ws,
+                  const SgmShape &P, bool vec, bool first, hipStream_t s) {
   const int waves = P.paths * P.batch;
   const dim3 grid((waves + kSgmBlock / kWave - 1) / (kSgmBlock / kWave)), block(kSgmBlock);
   if (vec && first)
-    hipLaunchKernelGGL((sgm_pass_kernel<VPL, true, true>), grid, block, 0, s, cost, image, out, P);
+    hipLaunchKernelGGL((sgm_pass_kernel<VPL, true, true>), grid, block, 0, s, cost, image, out, ws, P);
   else if (vec)
-    hipLaunchKernelGGL((sgm_pass_kernel<VPL, true, false>), grid, block, 0, s, cost, image, out, P);
+    hipLaunchKernelGGL((sgm_pass_kernel<VPL, true, false>), grid, block, 0, s, cost, image, out, ws, P);
   else if (first)
-    hipLaunchKernelGGL((sgm_pass_kernel<VPL, false, true>), grid, block, 0, s, cost, image, out, P);
+    hipLaunchKernelGGL((sgm_pass_kernel<VPL, false, true>), grid, block, 0, s, cost, image, out, ws, P);
   else
-    hipLaunchKernelGGL((sgm_pass_kernel<VPL, false, false>), grid, block, 0, s, cost, image, out, P);
+    hipLaunchKernelGGL((sgm_pass_kernel<VPL, false, false>), grid, block, 0, s, cost, image, out, ws, P);
   return check_launch("stm_sgm_f32");
+}
+
+int launch_repeat(float *out, const float *ws, const SgmShape &P, int x0, int y0, int dx, int dy,
+                  int len, int count, hipStream_t s) {
+  SgmRepeat R;
+  R.H = P.H; R.W = P.W; R.D = P.D; R.batch = P.batch; R.ws_rows = P.ws_rows;
+  R.x0 = x0; R.y0 = y0; R.dx = dx; R.dy = dy; R.len = len; R.count = count;
+  const long n = (long)len * P.D;
+  hipLaunchKernelGGL(sgm_repeat_kernel, dim3((unsigned)((n + 255) / 256), P.batch), dim3(256), 0, s,
+                     out, ws, R);
+  return check_launch("stm_sgm_f32 (repeat)");
 }
 
 }  // namespace
 }  // namespace stm
 
+static size_t sgm_ws_bytes(int H, int W, int D, int batch) {
+  const stm::SgmQuirk q = stm::sgm_quirk(H, W);
+  if (q.wide_extra == 0 && q.tall_extra == 0) return 0;
+  return (size_t)batch * (size_t)(H < W ? H : W) * (size_t)D * sizeof(float);
+}
+
 extern "C" size_t stm_sgm_workspace_bytes(int H, int W, int D, int batch, int flags) {
-  (void)H; (void)W; (void)D; (void)batch; (void)flags;
-  return 0;  // the path-parallel passes need no scratch
+  (void)flags;
+  if (H <= 0 || W <= 0 || D <= 0 || batch <= 0) return 0;
+  return sgm_ws_bytes(H, W, D, batch);
 }
 
 extern "C" int stm_sgm_f32(const float *cost, const float *left, float *out, int H, int W,
                            int D, float penalty1, float penalty2, int flags, void *workspace,
                            size_t workspace_bytes, int batch, void *stream) {
   using namespace stm;
-  (void)workspace; (void)workspace_bytes;
   STM_REQUIRE(cost && left && out, STM_EINVAL, "stm_sgm_f32: null pointer");
   STM_REQUIRE(H > 0 && W > 0 && D > 0 && batch > 0, STM_EINVAL,
               "stm_sgm_f32: non-positive size (H=%d W=%d D=%d batch=%d)", H, W, D, batch);
@@ -344,30 +394,45 @@ extern "C" int stm_sgm_f32(const float *cost, const float *left, float *out, int
   // The reference stores path coordinates as int16 (src/semiglobal.hpp:34-36).
   STM_REQUIRE(H < 32768 && W < 32768, STM_EUNSUPPORTED,
               "stm_sgm_f32: image side exceeds the reference's int16 path coordinates");
-  STM_REQUIRE((long long)batch * (W + H) < (1ll << 30), STM_EUNSUPPORTED,
+  STM_REQUIRE((long long)batch * (W + H) < (1ll << 30) && batch <= 65535, STM_EUNSUPPORTED,
               "stm_sgm_f32: too many paths in one launch");
+  const size_t need = sgm_ws_bytes(H, W, D, batch);
+  STM_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), STM_EWORKSPACE,
+              "stm_sgm_f32: needs a workspace of %zu bytes (stm_sgm_workspace_bytes)", need);
+  float *ws = need ? static_cast<float *>(workspace) : nullptr;
   const int vpl = (D + kWave - 1) / kWave;
   int VPL = 1;
   while (VPL < vpl) VPL <<= 1;  // 1, 2, 4, 8, 16
   const uintptr_t align = VPL >= 4 ? 15 : (VPL == 2 ? 7 : 3);
   const bool vec = (D == VPL * kWave) &&
                    ((reinterpret_cast<uintptr_t>(cost) & align) == 0) &&
-                   ((reinterpret_cast<uintptr_t>(out) & align) == 0);
+                   ((reinterpret_cast<uintptr_t>(out) & align) == 0) &&
+                   (!ws || (reinterpret_cast<uintptr_t>(ws) & align) == 0);
   hipStream_t s = as_stream(stream);
+  const SgmQuirk quirk = sgm_quirk(H, W);
   SgmShape P;
   P.H = H; P.W = W; P.D = D; P.p1 = penalty1; P.p2 = penalty2; P.batch = batch;
+  P.ws_rows = need ? (H < W ? H : W) : 0;
   for (int family = 0; family < 8; ++family) {
     P.family = family;
     P.paths = sgm_family_paths(family, H, W);
     const bool first = family == 0 && !(flags & STM_SGM_ACCUMULATE);
     int rc;
     switch (VPL) {
-      case 1: rc = launch_family<1>(cost, left, out, P, vec, first, s); break;
-      case 2: rc = launch_family<2>(cost, left, out, P, vec, first, s); break;
-      case 4: rc = launch_family<4>(cost, left, out, P, vec, first, s); break;
-      case 8: rc = launch_family<8>(cost, left, out, P, vec, first, s); break;
-      default: rc = launch_family<16>(cost, left, out, P, vec, first, s); break;
+      case 1: rc = launch_family<1>(cost, left, out, ws, P, vec, first, s); break;
+      case 2: rc = launch_family<2>(cost, left, out, ws, P, vec, first, s); break;
+      case 4: rc = launch_family<4>(cost, left, out, ws, P, vec, first, s); break;
+      case 8: rc = launch_family<8>(cost, left, out, ws, P, vec, first, s); break;
+      default: rc = launch_family<16>(cost, left, out, ws, P, vec, first, s); break;
     }
+    if (rc != STM_OK) return rc;
+    // Re-walked diagonals (Q6): the repeated adds go where the table order puts them.
+    if (family == kUp && quirk.tall_extra > 0)
+      rc = launch_repeat(out, ws, P, W - 1, H - 1, -1, -1, W, quirk.tall_extra, s);
+    else if (family == kUpLeft && quirk.wide_extra > 0)
+      rc = launch_repeat(out, ws, P, W - 1, H - 1, -1, -1, H, quirk.wide_extra, s);
+    else if (family == kUpRight && quirk.wide_extra > 0)
+      rc = launch_repeat(out, ws, P, 0, H - 1, 1, -1, H, quirk.wide_extra, s);
     if (rc != STM_OK) return rc;
   }
   return STM_OK;

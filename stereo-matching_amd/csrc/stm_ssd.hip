@@ -74,11 +74,26 @@ __global__ __launch_bounds__(256) void ssd_classify_kernel(const float *__restri
   lo = wave_min_i32(lo);
   hi = -wave_min_i32(hi == (-0x7fffffff - 1) ? 0x7fffffff : -hi);
   const unsigned long long anybad = __ballot(bad);
+  // One set of atomics per workgroup: the three words are shared by the whole grid.
+  __shared__ int s_lo[4], s_hi[4], s_bad[4];
+  const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
-    if (anybad) atomicOr(&ws->nonint, 1);
-    if (lo != 0x7fffffff) {
-      atomicMin(&ws->vmin, lo);
-      atomicMax(&ws->vmax, hi);
+    s_lo[wave] = lo;
+    s_hi[wave] = hi;
+    s_bad[wave] = anybad ? 1 : 0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int blo = s_lo[0], bhi = s_hi[0], bbad = s_bad[0];
+    for (int w = 1; w < 4; ++w) {
+      blo = s_lo[w] < blo ? s_lo[w] : blo;
+      bhi = s_hi[w] > bhi ? s_hi[w] : bhi;
+      bbad |= s_bad[w];
+    }
+    if (bbad) atomicOr(&ws->nonint, 1);
+    if (blo != 0x7fffffff) {
+      atomicMin(&ws->vmin, blo);
+      atomicMax(&ws->vmax, bhi);
     }
   }
 }
@@ -271,7 +286,7 @@ extern "C" int stm_ssd_f32(const float *left, const float *right, float *cost, i
     hipLaunchKernelGGL(ssd_class_init_kernel, dim3(1), dim3(1), 0, s, ws);
     const size_t n = (size_t)batch * H * W;
     size_t blocks = (2 * n + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(ssd_classify_kernel, dim3((unsigned)blocks), dim3(256), 0, s, left, right, n, ws);
   }
   const dim3 grid((W + kSsdTW - 1) / kSsdTW, H, batch), block(kSsdBlock);
