@@ -1,0 +1,65 @@
+"""N > 1 path on CPU: two gloo ranks shard a stack of stereo pairs with
+stereomatch.distributed, run a pipeline on their block and all-gather the disparity maps.
+The per-rank compute uses oracle-backed callables (the product ops are GPU-only); the
+sharding, the gather and Pipeline are the product's."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_pairs, H, W, D, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "stereo-matching_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import oracle
+    import stereomatch
+    from stereomatch.distributed import estimate_sharded, pair_shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def cost(left, right, cost_volume=None):
+        return torch.from_numpy(np.stack([oracle.ssd(l.numpy(), r.numpy(), D, 3)
+                                          for l, r in zip(left, right)]))
+
+    def reduce(volume, disparity_img=None):
+        return torch.from_numpy(np.stack([oracle.wta(v.numpy()) for v in volume]))
+
+    pairs = [oracle.synthetic_pair(H, W, seed=s) for s in range(n_pairs)]
+    lefts = torch.from_numpy(np.stack([p[0] for p in pairs]))
+    rights = torch.from_numpy(np.stack([p[1] for p in pairs]))
+    pipe = stereomatch.Pipeline(cost, reduce)
+    gathered = estimate_sharded(pipe, lefts, rights)
+    a, b = pair_shard(n_pairs, rank, world)
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), gathered.numpy())
+    np.save(os.path.join(out_dir, "span%d.npy" % rank), np.array([a, b]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_pairs", [4, 5])
+def test_two_ranks_shard_and_gather(tmp_path, oracle, n_pairs):
+    H, W, D, world = 12, 20, 8, 2
+    mp.spawn(_worker, args=(world, _free_port(), n_pairs, H, W, D, str(tmp_path)), nprocs=world,
+             join=True)
+    want = np.stack([oracle.wta(oracle.ssd(*oracle.synthetic_pair(H, W, seed=s), D, 3))
+                     for s in range(n_pairs)])
+    spans = [tuple(np.load(tmp_path / ("span%d.npy" % r))) for r in range(world)]
+    assert spans[0][0] == 0 and spans[0][1] == spans[1][0] and spans[1][1] == n_pairs
+    for r in range(world):
+        got = np.load(tmp_path / ("rank%d.npy" % r))
+        assert got.shape == want.shape and np.array_equal(got, want)

@@ -266,3 +266,28 @@ def test_batched_calls_equal_per_pair_calls(device, oracle):
         assert_same_bits(dpd[b].cpu().numpy(), oracle.dp(Sb, mode=1), "batched dp")
         assert_same_bits(B_[b].cpu().numpy(), oracle.birchfield(pairs[b][0], pairs[b][1], D),
                          "batched birchfield")
+
+
+# ------------------------------------------------------- committed golden fixtures
+@pytest.mark.parametrize("name", ["tiny_wide", "tiny_tall", "dp_square"])
+def test_gpu_matches_committed_golden_vectors(device, name):
+    """tests/golden/*.npz hold full tensors made by make_golden.py from the pinned oracle;
+    this comparison does not involve the oracle at run time."""
+    import os
+    import stereomatch
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    D, k = int(z["D"]), int(z["k"])
+    L, R = _gpu(z["left"], device), _gpu(z["right"], device)
+    for mode in ("ordered", "box", "auto"):
+        C = stereomatch.cost.SSD(D, kernel_size=k, mode=mode)(L, R)
+        assert_same_bits(C.cpu().numpy(), z["ssd"], "golden ssd " + mode)
+    assert_same_bits(stereomatch.cost.Birchfield(D)(L, R).cpu().numpy(), z["birchfield"], "golden bt")
+    S = stereomatch.aggregation.Semiglobal()(C, L)
+    assert_same_bits(S.cpu().numpy(), z["sgm"], "golden sgm")
+    wta = stereomatch.disparity_reduce.WinnerTakesAll()(S)
+    assert_same_bits(wta.cpu().numpy(), z["wta"], "golden wta")
+    dpc = stereomatch.disparity_reduce.DynamicProgramming(mode="corrected")(S)
+    assert_same_bits(dpc.cpu().numpy(), z["dp_corrected"], "golden dp corrected")
+    if "dp" in z.files:
+        dpr = stereomatch.disparity_reduce.DynamicProgramming()(S)
+        assert_same_bits(dpr.cpu().numpy(), z["dp"], "golden dp")
