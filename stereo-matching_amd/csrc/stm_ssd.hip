@@ -36,6 +36,7 @@ constexpr int kSsdMaxK = 16;     // window half-size covered (2k <= 32 <= lanes 
 
 struct SsdShape {
   int H, W, D, k, batch;
+  int slide_pair;  // AUTO only: 1 when an ssd_slide_kernel launch handles the exact-BOX case
   int lw;  // floats per staged left row  = TW + 2k
   int rw;  // floats per staged right row = TW + 2k + D - 1
 };
@@ -234,9 +235,13 @@ __global__ __launch_bounds__(kSsdBlock) void ssd_kernel(const float *__restrict_
   float *Ls = smem;
   float *Rs = Ls + 2 * S.k * S.lw;
   float *ring = Rs + 2 * S.k * S.rw;
-  ssd_stage(L, R, S, r, c0, Ls, Rs);
   bool box = MODE == STM_SSD_BOX;
-  if (MODE == STM_SSD_AUTO) box = ssd_box_is_exact(ws, S.k);
+  if (MODE == STM_SSD_AUTO) {
+    box = ssd_box_is_exact(ws, S.k);
+    // A sliding-form launch covers the exact-BOX case (k = 7, D % 64 == 0).
+    if (box && S.slide_pair) return;
+  }
+  ssd_stage(L, R, S, r, c0, Ls, Rs);
   if (box) {
     ssd_box_body(S, r, c0, Ls, Rs, ring, C);
   } else if (S.k == 7) {
@@ -244,6 +249,181 @@ __global__ __launch_bounds__(kSsdBlock) void ssd_kernel(const float *__restrict_
   } else {
     ssd_ordered_body<0>(S, r, c0, Ls, Rs, C);
   }
+}
+
+
+// ---------------------------------------------------------------------------------
+// BOX, sliding form (k = 7, D a multiple of 64): the fast path for integer-valued
+// images.  A wave owns a strip of kSlideCW output columns and 64 disparities and walks
+// down a band of rows.  Per lane it keeps the vertical window sums
+//     V[t] = sum over the 2k window rows of (L[row][kc] - R[row][kc-d])^2,  kc = c0-k+t
+// for the kSlideCW + 2k - 1 columns the strip's windows touch, in registers.  Moving down
+// one row adds the entering row and subtracts the leaving one (2 x 3 VALU per column);
+// the outputs of a row are a sliding horizontal sum over V (2 VALU per output).  The left
+// sample of a tap is wave-uniform and comes from scalar loads; the right sample
+// R[row][kc-d] of lane d at column kc+1 is what lane d-1 held at column kc, so the right
+// scanline lives in one register that is shifted by a DPP wave_shr:1 per column, with the
+// one new element (for the chunk's first disparity) fed from a scalar load.  No LDS, no
+// barriers; every store of cost[r][c][d0..d0+63] is a contiguous 256-byte burst.
+// All sums are exact integers <= 2^24 under the classifier's condition, so the result is
+// bit-identical to the ordered sum.  ~17 VALU per output: bound by the 4-byte store.
+constexpr int kSlideK = 7;
+constexpr int kSlideCW = 64;
+constexpr int kSlideNV = kSlideCW + 2 * kSlideK - 1;  // 77 window columns per strip
+
+struct SlideShape {
+  int H, W, D, batch;
+  int tiles, chunks, bands, band_h;
+  int mode;
+};
+
+// Row samples a strip needs from one image row, in registers: the left row segment
+// L[row][c0-k+i] (i = lane, lane+64) for the v_readlane hand-out and the right row segment
+// R[row][c0-k-(d0+63)+i] (i = lane, lane+64, lane+128) that is staged through LDS.
+// Rows outside the image (or not yet part of the band's window) read as zeros on both
+// sides, so they contribute (0-0)^2 = 0 and need no separate code path.
+struct SlideRow {
+  float l0, l1, r0, r1, r2;
+};
+
+__device__ __forceinline__ SlideRow slide_fetch(const float *__restrict__ L,
+                                                const float *__restrict__ R, int row, bool live,
+                                                int W, int c0, int d0, int lane) {
+  SlideRow q;
+  const float *Lrow = L + (size_t)(live ? row : 0) * W;
+  const float *Rrow = R + (size_t)(live ? row : 0) * W;
+  const int lc = c0 - kSlideK + lane;
+  const int rc = c0 - kSlideK - (d0 + 63) + lane;
+  q.l0 = (live && lc >= 0 && lc < W) ? Lrow[lc] : 0.0f;
+  q.l1 = (live && lane < kSlideNV - 64 && lc + 64 >= 0 && lc + 64 < W) ? Lrow[lc + 64] : 0.0f;
+  q.r0 = (live && rc >= 0 && rc < W) ? Rrow[rc] : 0.0f;
+  q.r1 = (live && rc + 64 >= 0 && rc + 64 < W) ? Rrow[rc + 64] : 0.0f;
+  q.r2 = (live && lane < kSlideNV + 63 - 128 && rc + 128 >= 0 && rc + 128 < W) ? Rrow[rc + 128] : 0.0f;
+  return q;
+}
+
+constexpr int kSlideRW = 144;  // staged right-row floats per row (kSlideNV + 63 = 140, padded)
+
+__device__ __forceinline__ void slide_stage(float *lds_row, const SlideRow &q, int lane) {
+  lds_row[lane] = q.r0;
+  lds_row[lane + 64] = q.r1;
+  if (lane < kSlideRW - 128) lds_row[lane + 128] = q.r2;
+}
+
+// One row step of a strip: V += Q[entering row] - Q[leaving row].
+// EDGE: the strip touches the left clip (kc >= d) or the right image border.
+template <bool EDGE>
+__device__ __forceinline__ void slide_step(float (&V)[kSlideNV], const SlideRow &e,
+                                           const SlideRow &x, const float *lds_e,
+                                           const float *lds_x, int W, int c0, int d, int lane) {
+  const int kc0 = c0 - kSlideK;
+#pragma unroll
+  for (int t = 0; t < kSlideNV; ++t) {
+    const float le = read_lane(t < 64 ? e.l0 : e.l1, t & 63);
+    const float lx = read_lane(t < 64 ? x.l0 : x.l1, t & 63);
+    const float de = le - lds_e[t + 63 - lane];
+    const float dx = lx - lds_x[t + 63 - lane];
+    float qe = de * de;
+    float qx = dx * dx;
+    if (EDGE) {
+      const int kc = kc0 + t;
+      const int lim = kc < W ? kc : -1;  // tap inside the window iff d <= kc < W
+      // Keep the compare next to its use: hoisted out of the row loop, the 77 lane masks
+      // would not fit the scalar register file.
+      int dd = d;
+      asm volatile("" : "+v"(dd));
+      const bool in = dd <= lim;
+      qe = in ? qe : 0.0f;
+      qx = in ? qx : 0.0f;
+    }
+    V[t] = (V[t] + qe) - qx;
+  }
+}
+
+template <bool EDGE>
+__device__ __forceinline__ void slide_band(const float *__restrict__ L, const float *__restrict__ R,
+                                           float *__restrict__ C, const SlideShape &S, int c0,
+                                           int d0, int d, int lane, int r_begin, int r_end,
+                                           float *lds) {
+  float V[kSlideNV];
+#pragma unroll
+  for (int t = 0; t < kSlideNV; ++t) V[t] = 0.0f;
+  const int W = S.W, H = S.H;
+  const int first_row = r_begin - kSlideK;  // first row of the band's first window
+  const float inf = __builtin_inff();
+  float *lds_e = lds, *lds_x = lds + kSlideRW;
+  // Iteration r brings V from the window of row r-1 to the window of row r:
+  // rows [r-k, r+k-1] = previous + row (r+k-1) - row (r-k-1).  The first 2k-1 iterations
+  // only build the first window (nothing leaves, nothing is stored).
+  int r = r_begin - (2 * kSlideK - 1);
+  auto live_enter = [&](int rr) { const int e = rr + kSlideK - 1; return e >= 0 && e < H && e >= first_row; };
+  auto live_leave = [&](int rr) { const int x = rr - kSlideK - 1; return x >= 0 && x >= first_row; };
+  SlideRow e = slide_fetch(L, R, r + kSlideK - 1, live_enter(r), W, c0, d0, lane);
+  SlideRow x = slide_fetch(L, R, r - kSlideK - 1, live_leave(r), W, c0, d0, lane);
+  for (; r < r_end; ++r) {
+    slide_stage(lds_e, e, lane);
+    slide_stage(lds_x, x, lane);
+    const SlideRow ce = e, cx = x;
+    // Next iteration's rows are in flight while this one computes.
+    e = slide_fetch(L, R, r + kSlideK, live_enter(r + 1) && r + 1 < r_end, W, c0, d0, lane);
+    x = slide_fetch(L, R, r - kSlideK, live_leave(r + 1) && r + 1 < r_end, W, c0, d0, lane);
+    slide_step<EDGE>(V, ce, cx, lds_e, lds_x, W, c0, d, lane);
+    if (r >= r_begin) {
+      // Outputs of row r: window columns [c-k, c+k) = V[c-c0 .. c-c0+2k-1].
+      float acc = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 2 * kSlideK; ++t) acc = acc + V[t];
+      float *out = C + ((size_t)r * W + c0) * S.D + d;
+#pragma unroll
+      for (int ci = 0; ci < kSlideCW; ++ci) {
+        if (ci > 0) acc = (acc - V[ci - 1]) + V[ci + 2 * kSlideK - 1];
+        if (!EDGE) {
+          out[(size_t)ci * S.D] = acc;
+        } else if (c0 + ci < W) {
+          int dd = d;
+          asm volatile("" : "+v"(dd));  // as above: no hoisted lane masks
+          out[(size_t)ci * S.D] = dd <= c0 + ci ? acc : inf;
+        }
+      }
+    }
+  }
+}
+
+// want_box: 1 = this launch computes when BOX is exact, and exits otherwise (AUTO pairs it
+// with an ORDERED launch that makes the opposite decision).
+__global__ __launch_bounds__(256) void ssd_slide_kernel(const float *__restrict__ L_all,
+                                                        const float *__restrict__ R_all,
+                                                        float *__restrict__ C_all,
+                                                        const SsdClass *__restrict__ ws,
+                                                        const SlideShape S) {
+  if (S.mode == STM_SSD_AUTO && !ssd_box_is_exact(ws, kSlideK)) return;
+  const int lane = threadIdx.x & 63;
+  int wave = wave_uniform((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int per_image = S.tiles * S.chunks * S.bands;
+  if (wave >= per_image * S.batch) return;
+  const int b = wave / per_image;
+  wave -= b * per_image;
+  const int chunk = wave % S.chunks;   // the waves of a workgroup share rows and columns
+  wave /= S.chunks;
+  const int tile = wave % S.tiles;
+  const int band = wave / S.tiles;
+  const size_t npix = (size_t)S.H * S.W;
+  const float *L = L_all + (size_t)b * npix;
+  const float *R = R_all + (size_t)b * npix;
+  float *C = C_all + (size_t)b * npix * S.D;
+  const int c0 = tile * kSlideCW;
+  const int d0 = chunk * 64;
+  const int d = d0 + lane;
+  const int r_begin = band * S.band_h;
+  const int r_end = r_begin + S.band_h < S.H ? r_begin + S.band_h : S.H;
+  // Interior strip: every tap of every lane is inside its window and inside the image.
+  const bool interior = (c0 - kSlideK >= d0 + 63) && (c0 + kSlideCW + kSlideK <= S.W);
+  __shared__ float slide_lds[4][2 * kSlideRW];
+  float *lds = slide_lds[threadIdx.x >> 6];
+  if (interior)
+    slide_band<false>(L, R, C, S, c0, d0, d, lane, r_begin, r_end, lds);
+  else
+    slide_band<true>(L, R, C, S, c0, d0, d, lane, r_begin, r_end, lds);
 }
 
 }  // namespace
@@ -288,6 +468,29 @@ extern "C" int stm_ssd_f32(const float *left, const float *right, float *cost, i
     size_t blocks = (2 * n + 255) / 256;
     if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(ssd_classify_kernel, dim3((unsigned)blocks), dim3(256), 0, s, left, right, n, ws);
+  }
+  // Sliding BOX form: k = 7 and whole 64-disparity chunks.
+  const bool can_slide = kernel_size == kSlideK && (D % 64) == 0 && mode != STM_SSD_ORDERED;
+  S.slide_pair = (can_slide && mode == STM_SSD_AUTO) ? 1 : 0;
+  if (can_slide) {
+    SlideShape T;
+    T.H = H; T.W = W; T.D = D; T.batch = batch; T.mode = mode;
+    T.tiles = (W + kSlideCW - 1) / kSlideCW;
+    T.chunks = D / 64;
+    // Bands short enough to fill the chip (>= ~4096 waves), tall enough to amortise the
+    // 13-row warm-up of a band.
+    long per_band = (long)T.tiles * T.chunks * batch;
+    int band_h = 64;
+    while (band_h > 16 && per_band * ((H + band_h - 1) / band_h) < 4096) band_h >>= 1;
+    T.band_h = band_h;
+    T.bands = (H + band_h - 1) / band_h;
+    const long waves = per_band * T.bands;
+    STM_REQUIRE(waves < (1l << 31), STM_EUNSUPPORTED, "stm_ssd_f32: too many strips");
+    hipLaunchKernelGGL(ssd_slide_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, left,
+                       right, cost, ws, T);
+    int rc = check_launch("stm_ssd_f32 (slide)");
+    if (rc != STM_OK) return rc;
+    if (mode == STM_SSD_BOX) return STM_OK;
   }
   const dim3 grid((W + kSsdTW - 1) / kSsdTW, H, batch), block(kSsdBlock);
   hipError_t err = hipSuccess;
