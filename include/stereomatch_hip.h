@@ -106,6 +106,12 @@ int stm_birchfield_f32(const float *left, const float *right, float *cost,
  *                       accumulating into zeros and saves one read of `out`.
  */
 #define STM_SGM_ACCUMULATE 1
+/*   STM_SGM_SINGLE_PASSES  run the eight direction families as eight separate passes over
+ *                       the sum (92N bytes of traffic) instead of the default paired
+ *                       form (a direction and its inverse share one read-modify-write;
+ *                       ~62N bytes, needs a larger workspace).  Same results bit for bit;
+ *                       kept for cross-checking and for callers short of memory. */
+#define STM_SGM_SINGLE_PASSES 2
 size_t stm_sgm_workspace_bytes(int H, int W, int D, int batch, int flags);
 int stm_sgm_f32(const float *cost, const float *left, float *out, int H, int W,
                 int D, float penalty1, float penalty2, int flags,

@@ -149,6 +149,38 @@ __device__ __forceinline__ Walk sgm_decode(int family, int w, int H, int W) {
   return k;
 }
 
+// One step of the recurrence, pixel i-1 -> pixel i of a path (semiglobal.cpp:129-157).
+template <int VPL>
+__device__ __forceinline__ Row<VPL> sgm_step(const Row<VPL> &prev, float prev_i, const Row<VPL> &c,
+                                             float inten, float p1, float p2, int D, int d0) {
+  const float inf = __builtin_inff();
+  // m over d in [0, D-2]: the element d = D-1 is left out (Q5).
+  float lm = inf;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j)
+    if (d0 + j < D - 1) lm = fminf(lm, prev.v[j]);
+  float m = wave_min_f32(lm);
+  if (D == 1) m = read_lane(prev.v[0], 0);  // empty range: *end() is element D-1
+  const float q = p2 / fabsf(inten - prev_i);
+  const float p2a = p1 < q ? q : p1;  // std::max(p1, q)
+  const float far = m + p2a;
+  const float below = lane_up(prev.v[VPL - 1], inf);  // L(d0-1)
+  const float above = lane_down(prev.v[0], inf);      // L(d0+VPL)
+  Row<VPL> cur;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const float lo = (j == 0 ? below : prev.v[j - 1]) + p1;
+    const float hi = (j == VPL - 1 ? above : prev.v[j + 1]) + p1;
+    float t = prev.v[j];
+    t = lo < t ? lo : t;  // get_min: strict '<' in argument order (cpp:11-16)
+    t = hi < t ? hi : t;
+    t = far < t ? far : t;
+    const float a = c.v[j] + t;
+    cur.v[j] = a - m;
+  }
+  return cur;
+}
+
 // One pass along one path.  FIRST: the output row is overwritten with
 // 0 + L (what accumulating into a zero-filled tensor gives) instead of
 // read-modify-written.
@@ -169,34 +201,8 @@ struct Walker {
     inten = image[q];
   }
 
-  // Pixel i > 0 of the path: semiglobal.cpp:129-157.
   __device__ __forceinline__ Row<VPL> advance(const Row<VPL> &c, float inten) const {
-    const float inf = __builtin_inff();
-    // m over d in [0, D-2]: the element d = D-1 is left out (Q5).
-    float lm = inf;
-#pragma unroll
-    for (int j = 0; j < VPL; ++j)
-      if (d0 + j < D - 1) lm = fminf(lm, prev.v[j]);
-    float m = wave_min_f32(lm);
-    if (D == 1) m = read_lane(prev.v[0], 0);  // empty range: *end() is element D-1
-    const float q = p2 / fabsf(inten - prev_i);
-    const float p2a = p1 < q ? q : p1;  // std::max(p1, q)
-    const float far = m + p2a;
-    const float below = lane_up(prev.v[VPL - 1], inf);  // L(d0-1)
-    const float above = lane_down(prev.v[0], inf);      // L(d0+VPL)
-    Row<VPL> cur;
-#pragma unroll
-    for (int j = 0; j < VPL; ++j) {
-      const float lo = (j == 0 ? below : prev.v[j - 1]) + p1;
-      const float hi = (j == VPL - 1 ? above : prev.v[j + 1]) + p1;
-      float t = prev.v[j];
-      t = lo < t ? lo : t;  // get_min: strict '<' in argument order (cpp:11-16)
-      t = hi < t ? hi : t;
-      t = far < t ? far : t;
-      const float a = c.v[j] + t;
-      cur.v[j] = a - m;
-    }
-    return cur;
+    return sgm_step<VPL>(prev, prev_i, c, inten, p1, p2, D, d0);
   }
 
   __device__ __forceinline__ void emit(long q, int i, const Row<VPL> &s, const Row<VPL> &cur,
@@ -339,6 +345,218 @@ __global__ __launch_bounds__(256) void sgm_repeat_kernel(float *__restrict__ out
   *o = acc;
 }
 
+// =================================================================================
+// Paired form: a direction and its inverse share one read-modify-write of the sum.
+//
+// The eight single-direction passes move 92N bytes because every pass re-reads and
+// re-writes the running sum.  A path's forward pass F and inverse pass I touch the same
+// pixels, and the reference adds them back to back (run(path); run(path.inverse())), so
+//     out(p) = (out(p) + L_F(p)) + L_I(p)
+// can be formed in one visit of p if L_F(p) is known while I walks back.  L_F depends on
+// everything before p, so a first launch (sgm_ckpt_kernel) walks every forward path once,
+// reading only the cost volume, and keeps the state after every K-th pixel (N/K floats
+// per family).  The second launch per pair (sgm_pair_kernel) walks each path from its far
+// end in segments of K pixels: it loads the segment's cost rows (and sum rows) into
+// registers, rebuilds L_F for the segment from the checkpoint, then walks I through the
+// same registers and writes the finished rows.  Same float operations in the same order as
+// the single passes -> identical bits; traffic 16N for the four checkpoint walks +
+// 8N + 3 x 12N for the pair launches + ~2N of checkpoints = ~62N.
+// K = 64 / VPL pixels keeps the three row arrays at 64 VGPRs each.
+// =================================================================================
+struct PairShape {
+  int H, W, D;
+  float p1, p2;
+  int batch;
+  int ws_rows;            // spill rows per image (0: none)
+  int pair;               // 0: (right,left) 1: (down,up) 2: (down-right,up-left) 3: (down-left,up-right)
+  int paths[4];           // forward paths per image and pair
+  int maxseg[4];          // checkpoint slots per path = ceil(maxlen / K) - 1
+  long long ckpt_off[4];  // float offset of each pair's checkpoint block in the workspace
+  int tall_extra;         // > 0: one extra wave walks the tall corner diagonal (spill only)
+};
+
+__host__ __device__ inline int sgm_pair_fwd(int pair) { return pair * 2; }      // kRight, kDown, kDownRight, kDownLeft
+__host__ __device__ inline int sgm_pair_inv(int pair) { return pair * 2 + 1; }  // kLeft, kUp, kUpLeft, kUpRight
+
+// Paths per pair as indexed by the forward family (the kUp extra wave is not a pair path).
+__host__ __device__ inline int sgm_pair_paths(int pair, int H, int W) {
+  return pair == 0 ? H : (pair == 1 ? W : W + H - 1);
+}
+
+template <int VPL, bool VEC>
+__global__ __launch_bounds__(kSgmBlock) void sgm_ckpt_kernel(const float *__restrict__ cost_all,
+                                                             const float *__restrict__ image_all,
+                                                             float *__restrict__ ws_all,
+                                                             const PairShape P) {
+  constexpr int K = 64 / VPL;
+  const int lane = threadIdx.x & (kWave - 1);
+  int wave = wave_uniform((int)(blockIdx.x * (kSgmBlock / kWave) + (threadIdx.x >> 6)));
+  const int per_image = P.paths[0] + P.paths[1] + P.paths[2] + P.paths[3] + (P.tall_extra > 0 ? 1 : 0);
+  if (wave >= per_image * P.batch) return;
+  const int b = wave / per_image;
+  wave -= b * per_image;
+  int pair = 0;
+  while (pair < 4 && wave >= P.paths[pair]) { wave -= P.paths[pair]; ++pair; }
+  const size_t npix = (size_t)P.H * P.W;
+  const float *cost = cost_all + (size_t)b * npix * P.D;
+  const float *image = image_all + (size_t)b * npix;
+  const int D = P.D, d0 = lane * VPL;
+
+  Walk k;
+  float *ckpt = nullptr;
+  float *spill = nullptr;
+  if (pair < 4) {
+    k = sgm_decode(sgm_pair_fwd(pair), wave, P.H, P.W);
+    ckpt = ws_all + P.ckpt_off[pair] + ((size_t)b * P.paths[pair] + wave) * (size_t)P.maxseg[pair] * D;
+  } else {
+    k = sgm_decode(kUp, P.W, P.H, P.W);  // the tall corner diagonal, spill only
+    spill = ws_all + (size_t)b * P.ws_rows * D;
+  }
+  if (k.len <= 0) return;
+  const long step = (long)k.dy * P.W + k.dx;
+  long pix = (long)k.y0 * P.W + k.x0;
+  const int last = k.len - 1;
+
+  Row<VPL> cbuf[kPF];
+  float ibuf[kPF];
+#pragma unroll
+  for (int u = 0; u < kPF; ++u) {
+    const long q = pix + (long)imin(u, last) * step;
+    cbuf[u] = load_row<VPL, VEC>(cost, (size_t)q, D, d0);
+    ibuf[u] = image[q];
+  }
+  Row<VPL> prev = cbuf[0];
+  float prev_i = ibuf[0];
+  if (spill) store_row<VPL, VEC>(spill, 0, D, d0, prev);
+  for (int base = 0; base < k.len; base += kPF) {
+#pragma unroll
+    for (int u = 0; u < kPF; ++u) {
+      const int i = base + u;
+      if (i < k.len) {
+        const Row<VPL> c = cbuf[u];
+        const float inten = ibuf[u];
+        {
+          const long q = pix + (long)imin(kPF, last - i) * step;
+          cbuf[u] = load_row<VPL, VEC>(cost, (size_t)q, D, d0);
+          ibuf[u] = image[q];
+        }
+        if (i > 0) {
+          const Row<VPL> cur = sgm_step<VPL>(prev, prev_i, c, inten, P.p1, P.p2, D, d0);
+          prev = cur;
+          prev_i = inten;
+          if (spill) store_row<VPL, VEC>(spill, (size_t)i, D, d0, cur);
+        }
+        // State after pixel i = what segment (i+1)/K starts from.
+        if (ckpt && ((i + 1) % K) == 0 && i + 1 < k.len)
+          store_row<VPL, VEC>(ckpt, (size_t)((i + 1) / K - 1), D, d0, prev);
+        pix += step;
+      }
+    }
+  }
+}
+
+template <int VPL, bool VEC, bool FIRST>
+__global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__restrict__ cost_all,
+                                                             const float *__restrict__ image_all,
+                                                             float *__restrict__ out_all,
+                                                             float *__restrict__ ws_all,
+                                                             const PairShape P) {
+  constexpr int K = 64 / VPL;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = wave_uniform((int)(blockIdx.x * (kSgmBlock / kWave) + (threadIdx.x >> 6)));
+  const int paths = P.paths[P.pair];
+  if (wave >= paths * P.batch) return;
+  const int b = wave / paths;
+  const int w = wave - b * paths;
+  const size_t npix = (size_t)P.H * P.W;
+  const float *cost = cost_all + (size_t)b * npix * P.D;
+  const float *image = image_all + (size_t)b * npix;
+  float *out = out_all + (size_t)b * npix * P.D;
+  const int D = P.D, d0 = lane * VPL;
+  const float p1 = P.p1, p2 = P.p2;
+
+  const Walk F = sgm_decode(sgm_pair_fwd(P.pair), w, P.H, P.W);
+  const Walk I = sgm_decode(sgm_pair_inv(P.pair), w, P.H, P.W);
+  if (F.len <= 0) return;
+  const bool add_inv = I.add != 0;  // 0: the reference's inverse pass re-walks another diagonal
+  float *spill = (I.spill && P.ws_rows > 0) ? ws_all + (size_t)b * P.ws_rows * D : nullptr;
+  const float *ckpt = ws_all + P.ckpt_off[P.pair] + ((size_t)b * paths + w) * (size_t)P.maxseg[P.pair] * D;
+  const long step = (long)F.dy * P.W + F.dx;
+  const long pix0 = (long)F.y0 * P.W + F.x0;
+  const int nseg = (F.len + K - 1) / K;
+
+  Row<VPL> inv_prev;
+  float inv_prev_i = 0.0f;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) inv_prev.v[j] = 0.0f;
+
+  for (int s = nseg - 1; s >= 0; --s) {
+    const int base = s * K;
+    const int n = imin(K, F.len - base);
+    Row<VPL> cseg[K], sseg[K], fseg[K];
+    float iseg[K];
+    // Bulk loads of the segment: everything a wave needs for K pixels is in flight at once.
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const long q = pix0 + (long)(base + imin(j, n - 1)) * step;
+      cseg[j] = load_row<VPL, VEC>(cost, (size_t)q, D, d0);
+      iseg[j] = image[q];
+    }
+    if constexpr (!FIRST) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const long q = pix0 + (long)(base + imin(j, n - 1)) * step;
+        sseg[j] = load_row<VPL, VEC>(out, (size_t)q, D, d0);
+      }
+    }
+    // Forward values of the segment, from the path start (s = 0) or the checkpoint.
+    Row<VPL> fprev;
+    float fprev_i;
+    if (s == 0) {
+      fprev = cseg[0];
+      fprev_i = iseg[0];
+    } else {
+      fprev = load_row<VPL, VEC>(ckpt, (size_t)(s - 1), D, d0);
+      fprev_i = image[pix0 + (long)(base - 1) * step];
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      if (j < n) {
+        if (s == 0 && j == 0) {
+          fseg[0] = cseg[0];
+        } else {
+          fseg[j] = sgm_step<VPL>(fprev, fprev_i, cseg[j], iseg[j], p1, p2, D, d0);
+          fprev = fseg[j];
+          fprev_i = iseg[j];
+        }
+      }
+    }
+    // Inverse walk through the same registers, finishing each row.
+#pragma unroll
+    for (int j = K - 1; j >= 0; --j) {
+      if (j < n) {
+        Row<VPL> o;
+#pragma unroll
+        for (int e = 0; e < VPL; ++e) o.v[e] = (FIRST ? 0.0f : sseg[j].v[e]) + fseg[j].v[e];
+        if (add_inv) {
+          Row<VPL> li;
+          if (s == nseg - 1 && j == n - 1) {
+            li = cseg[j];  // first pixel of the inverse pass: L = C
+          } else {
+            li = sgm_step<VPL>(inv_prev, inv_prev_i, cseg[j], iseg[j], p1, p2, D, d0);
+          }
+          inv_prev = li;
+          inv_prev_i = iseg[j];
+#pragma unroll
+          for (int e = 0; e < VPL; ++e) o.v[e] = o.v[e] + li.v[e];
+          if (spill) store_row<VPL, VEC>(spill, (size_t)(F.len - 1 - (base + j)), D, d0, li);
+        }
+        store_row<VPL, VEC>(out, (size_t)(pix0 + (long)(base + j) * step), D, d0, o);
+      }
+    }
+  }
+}
+
 template <int VPL>
 int launch_family(const float *cost, const float *image, float *out, float *ws,
                   const SgmShape &P, bool vec, bool first, hipStream_t s) {
@@ -355,13 +573,13 @@ int launch_family(const float *cost, const float *image, float *out, float *ws,
   return check_launch("stm_sgm_f32");
 }
 
-int launch_repeat(float *out, const float *ws, const SgmShape &P, int x0, int y0, int dx, int dy,
-                  int len, int count, hipStream_t s) {
+int launch_repeat(float *out, const float *ws, int H, int W, int D, int batch, int ws_rows, int x0,
+                  int y0, int dx, int dy, int len, int count, hipStream_t s) {
   SgmRepeat R;
-  R.H = P.H; R.W = P.W; R.D = P.D; R.batch = P.batch; R.ws_rows = P.ws_rows;
+  R.H = H; R.W = W; R.D = D; R.batch = batch; R.ws_rows = ws_rows;
   R.x0 = x0; R.y0 = y0; R.dx = dx; R.dy = dy; R.len = len; R.count = count;
-  const long n = (long)len * P.D;
-  hipLaunchKernelGGL(sgm_repeat_kernel, dim3((unsigned)((n + 255) / 256), P.batch), dim3(256), 0, s,
+  const long n = (long)len * D;
+  hipLaunchKernelGGL(sgm_repeat_kernel, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, s,
                      out, ws, R);
   return check_launch("stm_sgm_f32 (repeat)");
 }
@@ -369,17 +587,82 @@ int launch_repeat(float *out, const float *ws, const SgmShape &P, int x0, int y0
 }  // namespace
 }  // namespace stm
 
-static size_t sgm_ws_bytes(int H, int W, int D, int batch) {
+// Workspace layout (floats): [spill rows: batch x min(H,W) x D, only when a diagonal is
+// re-walked] [checkpoints of pair 0] [pair 1] [pair 2] [pair 3]; a pair's block is
+// batch x paths x maxseg x D.
+struct SgmPlan {
+  size_t spill_floats;
+  size_t total_floats;
+  stm::PairShape P;
+};
+
+static int sgm_vpl(int D) {
+  const int vpl = (D + stm::kWave - 1) / stm::kWave;
+  int VPL = 1;
+  while (VPL < vpl) VPL <<= 1;  // 1, 2, 4, 8, 16
+  return VPL;
+}
+
+static SgmPlan sgm_plan(int H, int W, int D, int batch, bool paired) {
+  SgmPlan plan;
   const stm::SgmQuirk q = stm::sgm_quirk(H, W);
-  if (q.wide_extra == 0 && q.tall_extra == 0) return 0;
-  return (size_t)batch * (size_t)(H < W ? H : W) * (size_t)D * sizeof(float);
+  const bool quirk = q.wide_extra > 0 || q.tall_extra > 0;
+  plan.spill_floats = quirk ? (size_t)batch * (size_t)(H < W ? H : W) * (size_t)D : 0;
+  stm::PairShape &P = plan.P;
+  P.H = H; P.W = W; P.D = D; P.batch = batch;
+  P.ws_rows = quirk ? (H < W ? H : W) : 0;
+  P.tall_extra = q.tall_extra;
+  P.pair = 0;
+  size_t off = plan.spill_floats;
+  const int K = 64 / sgm_vpl(D);
+  for (int pair = 0; pair < 4; ++pair) {
+    const int maxlen = pair == 0 ? W : (pair == 1 ? H : (H < W ? H : W));
+    P.paths[pair] = stm::sgm_pair_paths(pair, H, W);
+    P.maxseg[pair] = (maxlen + K - 1) / K - 1;
+    P.ckpt_off[pair] = (long long)off;
+    if (paired) off += (size_t)batch * P.paths[pair] * (size_t)P.maxseg[pair] * (size_t)D;
+  }
+  plan.total_floats = off;
+  return plan;
 }
 
 extern "C" size_t stm_sgm_workspace_bytes(int H, int W, int D, int batch, int flags) {
-  (void)flags;
-  if (H <= 0 || W <= 0 || D <= 0 || batch <= 0) return 0;
-  return sgm_ws_bytes(H, W, D, batch);
+  if (H <= 0 || W <= 0 || D <= 0 || batch <= 0 || D > STM_MAX_DISPARITY) return 0;
+  return sgm_plan(H, W, D, batch, !(flags & STM_SGM_SINGLE_PASSES)).total_floats * sizeof(float);
 }
+
+namespace stm {
+namespace {
+
+template <int VPL>
+int launch_ckpt(const float *cost, const float *image, float *ws, const PairShape &P, bool vec,
+                hipStream_t s) {
+  const long waves = (long)(P.paths[0] + P.paths[1] + P.paths[2] + P.paths[3] +
+                            (P.tall_extra > 0 ? 1 : 0)) * P.batch;
+  const dim3 grid((unsigned)((waves + kSgmBlock / kWave - 1) / (kSgmBlock / kWave))), block(kSgmBlock);
+  if (vec) hipLaunchKernelGGL((sgm_ckpt_kernel<VPL, true>), grid, block, 0, s, cost, image, ws, P);
+  else hipLaunchKernelGGL((sgm_ckpt_kernel<VPL, false>), grid, block, 0, s, cost, image, ws, P);
+  return check_launch("stm_sgm_f32 (checkpoints)");
+}
+
+template <int VPL>
+int launch_pair(const float *cost, const float *image, float *out, float *ws, const PairShape &P,
+                bool vec, bool first, hipStream_t s) {
+  const long waves = (long)P.paths[P.pair] * P.batch;
+  const dim3 grid((unsigned)((waves + kSgmBlock / kWave - 1) / (kSgmBlock / kWave))), block(kSgmBlock);
+  if (vec && first)
+    hipLaunchKernelGGL((sgm_pair_kernel<VPL, true, true>), grid, block, 0, s, cost, image, out, ws, P);
+  else if (vec)
+    hipLaunchKernelGGL((sgm_pair_kernel<VPL, true, false>), grid, block, 0, s, cost, image, out, ws, P);
+  else if (first)
+    hipLaunchKernelGGL((sgm_pair_kernel<VPL, false, true>), grid, block, 0, s, cost, image, out, ws, P);
+  else
+    hipLaunchKernelGGL((sgm_pair_kernel<VPL, false, false>), grid, block, 0, s, cost, image, out, ws, P);
+  return check_launch("stm_sgm_f32 (pair)");
+}
+
+}  // namespace
+}  // namespace stm
 
 extern "C" int stm_sgm_f32(const float *cost, const float *left, float *out, int H, int W,
                            int D, float penalty1, float penalty2, int flags, void *workspace,
@@ -394,15 +677,15 @@ extern "C" int stm_sgm_f32(const float *cost, const float *left, float *out, int
   // The reference stores path coordinates as int16 (src/semiglobal.hpp:34-36).
   STM_REQUIRE(H < 32768 && W < 32768, STM_EUNSUPPORTED,
               "stm_sgm_f32: image side exceeds the reference's int16 path coordinates");
-  STM_REQUIRE((long long)batch * (W + H) < (1ll << 30) && batch <= 65535, STM_EUNSUPPORTED,
+  STM_REQUIRE((long long)batch * (W + H) < (1ll << 28) && batch <= 65535, STM_EUNSUPPORTED,
               "stm_sgm_f32: too many paths in one launch");
-  const size_t need = sgm_ws_bytes(H, W, D, batch);
+  const bool paired = !(flags & STM_SGM_SINGLE_PASSES);
+  SgmPlan plan = sgm_plan(H, W, D, batch, paired);
+  const size_t need = plan.total_floats * sizeof(float);
   STM_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), STM_EWORKSPACE,
               "stm_sgm_f32: needs a workspace of %zu bytes (stm_sgm_workspace_bytes)", need);
   float *ws = need ? static_cast<float *>(workspace) : nullptr;
-  const int vpl = (D + kWave - 1) / kWave;
-  int VPL = 1;
-  while (VPL < vpl) VPL <<= 1;  // 1, 2, 4, 8, 16
+  const int VPL = sgm_vpl(D);
   const uintptr_t align = VPL >= 4 ? 15 : (VPL == 2 ? 7 : 3);
   const bool vec = (D == VPL * kWave) &&
                    ((reinterpret_cast<uintptr_t>(cost) & align) == 0) &&
@@ -410,14 +693,52 @@ extern "C" int stm_sgm_f32(const float *cost, const float *left, float *out, int
                    (!ws || (reinterpret_cast<uintptr_t>(ws) & align) == 0);
   hipStream_t s = as_stream(stream);
   const SgmQuirk quirk = sgm_quirk(H, W);
+  const bool accumulate = (flags & STM_SGM_ACCUMULATE) != 0;
+  int rc = STM_OK;
+
+  if (paired) {
+    PairShape &P = plan.P;
+    P.p1 = penalty1; P.p2 = penalty2;
+    switch (VPL) {
+      case 1: rc = launch_ckpt<1>(cost, left, ws, P, vec, s); break;
+      case 2: rc = launch_ckpt<2>(cost, left, ws, P, vec, s); break;
+      case 4: rc = launch_ckpt<4>(cost, left, ws, P, vec, s); break;
+      case 8: rc = launch_ckpt<8>(cost, left, ws, P, vec, s); break;
+      default: rc = launch_ckpt<16>(cost, left, ws, P, vec, s); break;
+    }
+    if (rc != STM_OK) return rc;
+    for (int pair = 0; pair < 4; ++pair) {
+      P.pair = pair;
+      const bool first = pair == 0 && !accumulate;
+      // Tall images: the corner diagonal's early re-walks precede the (1,1) forward pass.
+      if (pair == 2 && quirk.tall_extra > 0) {
+        rc = launch_repeat(out, ws, H, W, D, batch, P.ws_rows, W - 1, H - 1, -1, -1, W, quirk.tall_extra, s);
+        if (rc != STM_OK) return rc;
+      }
+      switch (VPL) {
+        case 1: rc = launch_pair<1>(cost, left, out, ws, P, vec, first, s); break;
+        case 2: rc = launch_pair<2>(cost, left, out, ws, P, vec, first, s); break;
+        case 4: rc = launch_pair<4>(cost, left, out, ws, P, vec, first, s); break;
+        case 8: rc = launch_pair<8>(cost, left, out, ws, P, vec, first, s); break;
+        default: rc = launch_pair<16>(cost, left, out, ws, P, vec, first, s); break;
+      }
+      if (rc != STM_OK) return rc;
+      if (pair == 2 && quirk.wide_extra > 0)
+        rc = launch_repeat(out, ws, H, W, D, batch, P.ws_rows, W - 1, H - 1, -1, -1, H, quirk.wide_extra, s);
+      else if (pair == 3 && quirk.wide_extra > 0)
+        rc = launch_repeat(out, ws, H, W, D, batch, P.ws_rows, 0, H - 1, 1, -1, H, quirk.wide_extra, s);
+      if (rc != STM_OK) return rc;
+    }
+    return STM_OK;
+  }
+
   SgmShape P;
   P.H = H; P.W = W; P.D = D; P.p1 = penalty1; P.p2 = penalty2; P.batch = batch;
-  P.ws_rows = need ? (H < W ? H : W) : 0;
+  P.ws_rows = plan.P.ws_rows;
   for (int family = 0; family < 8; ++family) {
     P.family = family;
     P.paths = sgm_family_paths(family, H, W);
-    const bool first = family == 0 && !(flags & STM_SGM_ACCUMULATE);
-    int rc;
+    const bool first = family == 0 && !accumulate;
     switch (VPL) {
       case 1: rc = launch_family<1>(cost, left, out, ws, P, vec, first, s); break;
       case 2: rc = launch_family<2>(cost, left, out, ws, P, vec, first, s); break;
@@ -428,11 +749,11 @@ extern "C" int stm_sgm_f32(const float *cost, const float *left, float *out, int
     if (rc != STM_OK) return rc;
     // Re-walked diagonals (Q6): the repeated adds go where the table order puts them.
     if (family == kUp && quirk.tall_extra > 0)
-      rc = launch_repeat(out, ws, P, W - 1, H - 1, -1, -1, W, quirk.tall_extra, s);
+      rc = launch_repeat(out, ws, P.H, P.W, P.D, P.batch, P.ws_rows, W - 1, H - 1, -1, -1, W, quirk.tall_extra, s);
     else if (family == kUpLeft && quirk.wide_extra > 0)
-      rc = launch_repeat(out, ws, P, W - 1, H - 1, -1, -1, H, quirk.wide_extra, s);
+      rc = launch_repeat(out, ws, P.H, P.W, P.D, P.batch, P.ws_rows, W - 1, H - 1, -1, -1, H, quirk.wide_extra, s);
     else if (family == kUpRight && quirk.wide_extra > 0)
-      rc = launch_repeat(out, ws, P, 0, H - 1, 1, -1, H, quirk.wide_extra, s);
+      rc = launch_repeat(out, ws, P.H, P.W, P.D, P.batch, P.ws_rows, 0, H - 1, 1, -1, H, quirk.wide_extra, s);
     if (rc != STM_OK) return rc;
   }
   return STM_OK;

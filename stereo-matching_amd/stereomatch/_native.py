@@ -16,6 +16,7 @@ ABI_VERSION = 1
 
 STM_SSD_MODES = {"auto": 0, "ordered": 1, "box": 2}
 STM_SGM_ACCUMULATE = 1
+STM_SGM_SINGLE_PASSES = 2
 STM_DP_MODES = {"reference": 0, "corrected": 1}
 
 # name -> (restype, argtypes); every symbol include/stereomatch_hip.h declares.

@@ -21,9 +21,12 @@ class Semiglobal:
     gives the same values without the extra fill and read.
     """
 
-    def __init__(self, penalty1: float = 0.1, penalty2: float = 0.2):
+    def __init__(self, penalty1: float = 0.1, penalty2: float = 0.2, single_passes: bool = False):
         self.penalty1 = penalty1
         self.penalty2 = penalty2
+        # False (default): a direction and its inverse share one pass over the sum (less HBM
+        # traffic, larger workspace); True: eight separate passes.  Same bits either way.
+        self.single_passes = single_passes
         self._workspace = None
 
     def __call__(self, cost_volume: torch.Tensor, left_image: torch.Tensor,
@@ -42,7 +45,8 @@ class Semiglobal:
         cost = cost_volume.contiguous()
         image = left_image.float().contiguous()
         lib = _native.lib()
-        ws_bytes = lib.stm_sgm_workspace_bytes(height, width, max_disparity, batch, 0)
+        flags = _native.STM_SGM_SINGLE_PASSES if self.single_passes else 0
+        ws_bytes = lib.stm_sgm_workspace_bytes(height, width, max_disparity, batch, flags)
         if ws_bytes and (self._workspace is None or self._workspace.device != device
                          or self._workspace.numel() < ws_bytes):
             self._workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
@@ -50,6 +54,6 @@ class Semiglobal:
         with torch.cuda.device(device):
             _native.check(lib.stm_sgm_f32(
                 cost.data_ptr(), image.data_ptr(), sga_volume.data_ptr(), height, width,
-                max_disparity, float(self.penalty1), float(self.penalty2), 0, ws_ptr, ws_bytes,
+                max_disparity, float(self.penalty1), float(self.penalty2), flags, ws_ptr, ws_bytes,
                 batch, _native.stream_ptr(device)))
         return sga_volume

@@ -55,7 +55,13 @@ def test_workspace_sizes():
     from stereomatch import _native
     lib = _native.lib()
     assert lib.stm_ssd_workspace_bytes(375, 450, 128, 7, 1) == 16
-    assert lib.stm_sgm_workspace_bytes(300, 300, 128, 1, 0) == 0           # square: no re-walks
-    assert lib.stm_sgm_workspace_bytes(301, 300, 128, 1, 0) == 0           # H = W+1: none either
-    assert lib.stm_sgm_workspace_bytes(375, 450, 128, 2, 0) == 2 * 375 * 128 * 4
-    assert lib.stm_sgm_workspace_bytes(450, 375, 128, 1, 0) == 375 * 128 * 4
+    single = 2  # STM_SGM_SINGLE_PASSES: only the spill rows of a re-walked diagonal
+    assert lib.stm_sgm_workspace_bytes(300, 300, 128, 1, single) == 0          # square: no re-walks
+    assert lib.stm_sgm_workspace_bytes(301, 300, 128, 1, single) == 0          # H = W+1: none either
+    assert lib.stm_sgm_workspace_bytes(375, 450, 128, 2, single) == 2 * 375 * 128 * 4
+    assert lib.stm_sgm_workspace_bytes(450, 375, 128, 1, single) == 375 * 128 * 4
+    # Paired form: + checkpoints every K = 64 / (D / 64) pixels for the four forward families.
+    H, W, D, K = 375, 450, 128, 32
+    seg = lambda n: (n + K - 1) // K - 1
+    ckpt = H * seg(W) + W * seg(H) + 2 * (W + H - 1) * seg(min(H, W))
+    assert lib.stm_sgm_workspace_bytes(H, W, D, 1, 0) == (H + ckpt) * D * 4

@@ -104,6 +104,9 @@ def test_1080p_sgm_full_volume_matches_oracle(device, oracle):
     L, R, Lg, Rg = _pair(oracle, H, W, device)
     C = stereomatch.cost.SSD(D)(Lg, Rg)
     S = stereomatch.aggregation.Semiglobal()(C, Lg)
+    S1 = stereomatch.aggregation.Semiglobal(single_passes=True)(C, Lg)
+    assert torch.equal(S.view(torch.int32), S1.view(torch.int32))   # paired == eight passes
+    del S1
     disp = stereomatch.disparity_reduce.WinnerTakesAll()(S)
     Ch = C.cpu().numpy()
     del C

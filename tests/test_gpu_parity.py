@@ -145,17 +145,23 @@ SGM_CASES = [(24, 40, 16), (40, 24, 16), (20, 20, 16), (21, 20, 8), (20, 22, 64)
              (10, 14, 100), (7, 9, 2), (6, 8, 1), (1, 9, 16), (9, 1, 16), (2, 2, 64)]
 
 
+SGM_CASES += [(70, 200, 64), (200, 70, 64), (40, 90, 128), (90, 40, 128), (35, 50, 256),
+              (50, 35, 256), (100, 101, 64), (101, 100, 64), (102, 100, 64), (33, 34, 512)]
+
+
 @pytest.mark.parametrize("H,W,D", SGM_CASES)
-def test_sgm_on_ssd_volume_matches_oracle(device, oracle, H, W, D):
+@pytest.mark.parametrize("single", [False, True])
+def test_sgm_on_ssd_volume_matches_oracle(device, oracle, H, W, D, single):
     import stereomatch
     L, R = oracle.synthetic_pair(H, W, seed=D + H)
     C = oracle.ssd(L, R, D, 3)
     want = oracle.sgm(C, L, 0.1, 0.2)
-    got = stereomatch.aggregation.Semiglobal(0.1, 0.2)(_gpu(C, device), _gpu(L, device))
+    sgm = stereomatch.aggregation.Semiglobal(0.1, 0.2, single_passes=single)
+    got = sgm(_gpu(C, device), _gpu(L, device))
     assert_same_bits(got.cpu().numpy(), want, "sgm ssd-volume")
 
 
-@pytest.mark.parametrize("H,W,D", SGM_CASES[:12])
+@pytest.mark.parametrize("H,W,D", SGM_CASES[:12] + SGM_CASES[17:23])
 @pytest.mark.parametrize("kind", ["float", "ties", "last"])
 def test_sgm_on_random_volume_matches_oracle(device, oracle, H, W, D, kind):
     import stereomatch
