@@ -187,6 +187,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="pairs per GPU per step (0 = default)")
     ap.add_argument("--also", default="1080p", help="second workload reported under 'also' ('' = none)")
     ap.add_argument("--also-steps", type=int, default=5)
+    ap.add_argument("--also-batch", type=int, default=0, help="pairs per step of the second workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -234,12 +235,13 @@ def main():
 
     if args.also and args.also != name and world == 1:
         w2 = WORKLOADS[args.also]
-        job2 = Job(args.also, w2["batch"], rank, device)
+        b2 = args.also_batch or w2["batch"]
+        job2 = Job(args.also, b2, rank, device)
         e2, s2 = timed_run(job2, args.also_steps, 1, 1)
         d7 = float((job2.disp == 7).float().mean())
         out["also"] = {
-            "workload": w2["config"], "value": round(w2["batch"] * args.also_steps / e2, 3),
-            "unit": "pairs/s", "pairs_per_step": w2["batch"], "steps": args.also_steps,
+            "workload": w2["config"], "value": round(b2 * args.also_steps / e2, 3),
+            "unit": "pairs/s", "pairs_per_step": b2, "steps": args.also_steps,
             "ms_per_step": round(e2 / args.also_steps * 1e3, 3),
             "stage_ms": {"ssd": round(s2[0], 4), "sgm": round(s2[1], 4), "wta": round(s2[2], 4)},
             "roofline": roofline(job2, s2[1], load_traffic(args.also)),

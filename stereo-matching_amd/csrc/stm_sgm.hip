@@ -41,6 +41,7 @@ namespace {
 
 constexpr int kSgmBlock = 256;
 constexpr int kPF = 4;  // pixels kept in flight per wave
+constexpr int kSegFloats = 32;  // floats per lane one segment row array occupies (K * VPL)
 
 enum Family : int {
   kRight = 0,      // group 1 forward   (1, 0)
@@ -171,10 +172,9 @@ __device__ __forceinline__ Row<VPL> sgm_step(const Row<VPL> &prev, float prev_i,
   for (int j = 0; j < VPL; ++j) {
     const float lo = (j == 0 ? below : prev.v[j - 1]) + p1;
     const float hi = (j == VPL - 1 ? above : prev.v[j + 1]) + p1;
-    float t = prev.v[j];
-    t = lo < t ? lo : t;  // get_min: strict '<' in argument order (cpp:11-16)
-    t = hi < t ? hi : t;
-    t = far < t ? far : t;
+    // get_min (cpp:11-16) is a strict-'<' chain; as a value that is the minimum of the
+    // four candidates (v_min3_f32 + v_min_f32).
+    const float t = fminf(fminf(fminf(prev.v[j], lo), hi), far);
     const float a = c.v[j] + t;
     cur.v[j] = a - m;
   }
@@ -363,6 +363,11 @@ __global__ __launch_bounds__(256) void sgm_repeat_kernel(float *__restrict__ out
 // 8N + 3 x 12N for the pair launches + ~2N of checkpoints = ~62N.
 // K = 64 / VPL pixels keeps the three row arrays at 64 VGPRs each.
 // =================================================================================
+// Pixels per segment of the paired form.
+__host__ __device__ constexpr int sgm_seg_len(int vpl) {
+  return kSegFloats / vpl > 4 ? kSegFloats / vpl : 4;
+}
+
 struct PairShape {
   int H, W, D;
   float p1, p2;
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_ckpt_kernel(const float *__rest
                                                              const float *__restrict__ image_all,
                                                              float *__restrict__ ws_all,
                                                              const PairShape P) {
-  constexpr int K = 64 / VPL;
+  constexpr int K = sgm_seg_len(VPL);
   const int lane = threadIdx.x & (kWave - 1);
   int wave = wave_uniform((int)(blockIdx.x * (kSgmBlock / kWave) + (threadIdx.x >> 6)));
   const int per_image = P.paths[0] + P.paths[1] + P.paths[2] + P.paths[3] + (P.tall_extra > 0 ? 1 : 0);
@@ -461,7 +466,7 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
                                                              float *__restrict__ out_all,
                                                              float *__restrict__ ws_all,
                                                              const PairShape P) {
-  constexpr int K = 64 / VPL;
+  constexpr int K = sgm_seg_len(VPL);
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = wave_uniform((int)(blockIdx.x * (kSgmBlock / kWave) + (threadIdx.x >> 6)));
   const int paths = P.paths[P.pair];
@@ -614,7 +619,7 @@ static SgmPlan sgm_plan(int H, int W, int D, int batch, bool paired) {
   P.tall_extra = q.tall_extra;
   P.pair = 0;
   size_t off = plan.spill_floats;
-  const int K = 64 / sgm_vpl(D);
+  const int K = stm::sgm_seg_len(sgm_vpl(D));
   for (int pair = 0; pair < 4; ++pair) {
     const int maxlen = pair == 0 ? W : (pair == 1 ? H : (H < W ? H : W));
     P.paths[pair] = stm::sgm_pair_paths(pair, H, W);

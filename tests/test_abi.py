@@ -60,8 +60,8 @@ def test_workspace_sizes():
     assert lib.stm_sgm_workspace_bytes(301, 300, 128, 1, single) == 0          # H = W+1: none either
     assert lib.stm_sgm_workspace_bytes(375, 450, 128, 2, single) == 2 * 375 * 128 * 4
     assert lib.stm_sgm_workspace_bytes(450, 375, 128, 1, single) == 375 * 128 * 4
-    # Paired form: + checkpoints every K = 64 / (D / 64) pixels for the four forward families.
-    H, W, D, K = 375, 450, 128, 32
+    # Paired form: + checkpoints every K = 32 / (D / 64) pixels for the four forward families.
+    H, W, D, K = 375, 450, 128, 16
     seg = lambda n: (n + K - 1) // K - 1
     ckpt = H * seg(W) + W * seg(H) + 2 * (W + H - 1) * seg(min(H, W))
     assert lib.stm_sgm_workspace_bytes(H, W, D, 1, 0) == (H + ckpt) * D * 4
