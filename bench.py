@@ -18,10 +18,12 @@ Multi-GPU: independent pairs are sharded over ranks (weak scaling: every rank ru
 same batch size); the only collective is the final all_gather of the int32 disparity
 maps over RCCL, inside the timed step.
 
-Rank 0 prints ONE JSON line.  ``roofline`` is for the semiglobal aggregation (the
-dominant kernel family, eight launches of sgm_pass_kernel per step): achieved =
-8 bytes x H*W*D x pairs  /  time of the eight launches, measured with HIP events on the
-launch stream inside the timed region.  ``cpu_baseline`` times the CPU oracle (1 thread,
+Rank 0 prints ONE JSON line.  ``roofline`` is for the semiglobal aggregation stage (the
+dominant kernels: one sgm_ckpt_kernel + four sgm_pair_kernel launches per step, the last
+with the winner-takes-all fused in): achieved = 8 bytes x H*W*D x pairs (SURVEY 8d's
+aggregation figure; the fused stage also does the reduction and skips the final write)
+/ time of those launches, measured with HIP events on the launch stream inside the timed
+region.  ``cpu_baseline`` times the CPU oracle (1 thread,
 the reference as shipped) on a bounded sample of the primary workload.
 """
 import argparse
@@ -45,7 +47,7 @@ WORKLOADS = {
     # digests: SURVEY.md Appendix C, SSD+SGM+WTA on the seed-0 pair (reference CPU output).
     "teddy": dict(H=375, W=450, D=128, batch=16, digest="9693be8fb6aa9b99",
                   config="Teddy 450x375, SSD + 8-path SGM + WTA, D=128"),
-    "1080p": dict(H=1080, W=1920, D=256, batch=2, digest=None,
+    "1080p": dict(H=1080, W=1920, D=256, batch=4, digest=None,
                   config="1920x1080 synthetic pair, SSD + SGM + WTA, D=256"),
 }
 
@@ -63,8 +65,23 @@ def digest16(t):
     return hashlib.sha256(np.ascontiguousarray(t).tobytes()).hexdigest()[:16]
 
 
+class _TimedCost:
+    """The cost callable of the pipeline, recording a HIP event when its work is queued."""
+
+    def __init__(self, op):
+        self.op, self.event = op, None
+
+    def __call__(self, left, right, cost_volume=None):
+        out = self.op(left, right, cost_volume=cost_volume)
+        if self.event is not None:
+            self.event.record()
+        return out
+
+
 class Job:
-    """Buffers and ops of one workload on one GPU."""
+    """Buffers and ops of one workload on one GPU: stereomatch.Pipeline(SSD, WTA, Semiglobal)
+    on a [B, H, W] stack of pairs.  With this package's own ops the pipeline runs the
+    aggregation and the winner-takes-all as one fused call (stm_sgm_wta_f32)."""
 
     def __init__(self, name, batch, rank, device):
         import stereomatch
@@ -74,10 +91,11 @@ class Job:
         pairs = [synthetic_pair(H, W, seed=rank * batch + b) for b in range(batch)]
         self.left = torch.from_numpy(np.stack([p[0] for p in pairs])).to(device)
         self.right = torch.from_numpy(np.stack([p[1] for p in pairs])).to(device)
-        self.ssd = stereomatch.cost.SSD(D, kernel_size=7)
+        self.cost_op = _TimedCost(stereomatch.cost.SSD(D, kernel_size=7))
         self.sgm = stereomatch.aggregation.Semiglobal(0.1, 0.2)
-        self.wta = stereomatch.disparity_reduce.WinnerTakesAll()
-        self.cost = self.agg = self.disp = None
+        self.pipe = stereomatch.Pipeline(self.cost_op, stereomatch.disparity_reduce.WinnerTakesAll(),
+                                         self.sgm)
+        self.disp = None
         self.gathered = None
         self.n_elems = H * W * D
 
@@ -85,15 +103,10 @@ class Job:
         ev = events
         if ev is not None:
             ev[0].record()
-        self.cost = self.ssd(self.left, self.right, cost_volume=self.cost)
-        if ev is not None:
-            ev[1].record()
-        self.agg = self.sgm(self.cost, self.left, self.agg)
+        self.cost_op.event = ev[1] if ev is not None else None
+        self.disp = self.pipe.estimate(self.left, self.right)
         if ev is not None:
             ev[2].record()
-        self.disp = self.wta(self.agg, self.disp)
-        if ev is not None:
-            ev[3].record()
         if world > 1:
             import torch.distributed as dist
             if self.gathered is None:
@@ -102,12 +115,26 @@ class Job:
             dist.all_gather_into_tensor(self.gathered, self.disp)
         return self.disp
 
+    def unfused_sgm_ms(self, reps=3):
+        """stm_sgm_f32 alone (aggregated volume written out) on the resident cost volume."""
+        out = None
+        self.sgm(self.pipe._cost_volume, self.left, out)
+        ms = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = self.sgm(self.pipe._cost_volume, self.left, out)
+            b.record()
+            torch.cuda.synchronize()
+            ms.append(a.elapsed_time(b))
+        return float(np.median(ms))
+
 
 def timed_run(job, steps, warmup, world):
     import torch.distributed as dist
     for _ in range(warmup):
         job.step(world=world)
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -122,14 +149,16 @@ def timed_run(job, steps, warmup, world):
         t = torch.tensor([elapsed], dtype=torch.float64, device=job.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    stage_ms = [float(np.mean([e[i].elapsed_time(e[i + 1]) for e in events])) for i in range(3)]
+    stage_ms = [float(np.mean([e[i].elapsed_time(e[i + 1]) for e in events])) for i in range(2)]
     return elapsed, stage_ms
 
 
 def roofline(job, sgm_ms, traffic=None):
     algorithmic = 8.0 * job.n_elems * job.batch  # read cost once + write sum once
     achieved = algorithmic / (sgm_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "sgm_pass_kernel (8 launches = one aggregation)",
+    return {"bound": "hbm",
+            "kernel": "semiglobal aggregation with fused WTA: sgm_ckpt_kernel + 4 x sgm_pair_kernel "
+                      "(stm_sgm_wta_f32)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes": algorithmic, "ms": round(sgm_ms, 4)}
@@ -226,8 +255,8 @@ def main():
         "config": {"workload": w["config"], "H": w["H"], "W": w["W"], "D": w["D"],
                    "pairs_per_gpu_per_step": batch, "ssd_mode": "auto", "kernel_size": 7,
                    "penalties": [0.1, 0.2], "sharding": "pairs over ranks, all_gather of disparity maps"},
-        "stage_ms": {"ssd": round(stage_ms[0], 4), "sgm": round(stage_ms[1], 4),
-                     "wta": round(stage_ms[2], 4)},
+        "stage_ms": {"ssd": round(stage_ms[0], 4), "sgm_wta_fused": round(stage_ms[1], 4),
+                     "sgm_alone_unfused": round(job.unfused_sgm_ms(), 4)},
         "roofline": roofline(job, stage_ms[1], load_traffic(name)),
     }
     del job
@@ -243,7 +272,8 @@ def main():
             "workload": w2["config"], "value": round(b2 * args.also_steps / e2, 3),
             "unit": "pairs/s", "pairs_per_step": b2, "steps": args.also_steps,
             "ms_per_step": round(e2 / args.also_steps * 1e3, 3),
-            "stage_ms": {"ssd": round(s2[0], 4), "sgm": round(s2[1], 4), "wta": round(s2[2], 4)},
+            "stage_ms": {"ssd": round(s2[0], 4), "sgm_wta_fused": round(s2[1], 4),
+                         "sgm_alone_unfused": round(job2.unfused_sgm_ms(), 4)},
             "roofline": roofline(job2, s2[1], load_traffic(args.also)),
             "pixels_at_true_disparity": round(d7, 4),
         }

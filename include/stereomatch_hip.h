@@ -118,6 +118,23 @@ int stm_sgm_f32(const float *cost, const float *left, float *out, int H, int W,
                 void *workspace, size_t workspace_bytes, int batch,
                 void *stream);
 
+/* ---- Fused aggregation + winner takes all (extension) -------------------------------
+ * What Pipeline(SSD, WinnerTakesAll, Semiglobal).estimate computes (stereomatch/
+ * pipeline.py:80-92 -> run_semiglobal then run_winners_take_all) in one call: the last
+ * direction pair of the aggregation reduces every finished row to its first-minimum
+ * disparity while it is still in registers, so the aggregated volume is neither written
+ * nor re-read (saves 8 of ~72 bytes per (pixel, d) of the SSD+SGM+WTA pipeline).
+ * `disparity` equals stm_sgm_f32 followed by stm_wta_f32 bit for bit.  `sum` is scratch
+ * of the aggregated volume's size; on return it holds the sum of the first six
+ * directions unless STM_SGM_KEEP_SUM asks for the finished sum.  Paired form only;
+ * workspace as stm_sgm_workspace_bytes(..., flags).
+ */
+#define STM_SGM_KEEP_SUM 4
+int stm_sgm_wta_f32(const float *cost, const float *left, float *sum,
+                    int32_t *disparity, int H, int W, int D, float penalty1,
+                    float penalty2, int flags, void *workspace,
+                    size_t workspace_bytes, int batch, void *stream);
+
 /* ---- Winner takes all (src/winners_take_all.cu:21-40) -------------------------
  * disparity[r][c] = index of the first minimum over d (strict '<' scan). */
 int stm_wta_f32(const float *volume, int32_t *disparity, int H, int W, int D,

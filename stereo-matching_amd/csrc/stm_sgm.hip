@@ -460,11 +460,15 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_ckpt_kernel(const float *__rest
   }
 }
 
-template <int VPL, bool VEC, bool FIRST>
+// FINAL (last pair only): 0 = write the finished sum rows; 1 = also reduce every finished
+// row to its first-minimum disparity (the winner-takes-all of src/winners_take_all.cu:21-40,
+// fused so the sum is not re-read); 2 = disparity only, the finished sum is never written.
+template <int VPL, bool VEC, bool FIRST, int FINAL>
 __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__restrict__ cost_all,
                                                              const float *__restrict__ image_all,
                                                              float *__restrict__ out_all,
                                                              float *__restrict__ ws_all,
+                                                             int32_t *__restrict__ disp_all,
                                                              const PairShape P) {
   constexpr int K = sgm_seg_len(VPL);
   const int lane = threadIdx.x & (kWave - 1);
@@ -556,10 +560,57 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
           for (int e = 0; e < VPL; ++e) o.v[e] = o.v[e] + li.v[e];
           if (spill) store_row<VPL, VEC>(spill, (size_t)(F.len - 1 - (base + j)), D, d0, li);
         }
-        store_row<VPL, VEC>(out, (size_t)(pix0 + (long)(base + j) * step), D, d0, o);
+        const long q = pix0 + (long)(base + j) * step;
+        // (The re-walked diagonal keeps its rows even in disparity-only mode: the repeat
+        // kernel finishes them.)
+        if (FINAL != 2 || spill) store_row<VPL, VEC>(out, (size_t)q, D, d0, o);
+        if constexpr (FINAL != 0) {
+          // Strict-'<' scan in register order, then lowest index among the lanes that hold
+          // the wave minimum; a NaN at d = 0 wins, as in the reference scan.
+          float best = __builtin_inff();
+          int idx = d0 < D ? d0 : 0x7fffffff;
+#pragma unroll
+          for (int e = 0; e < VPL; ++e)
+            if (d0 + e < D && o.v[e] < best) { best = o.v[e]; idx = d0 + e; }
+          const float m = wave_min_f32(best);
+          const int win = wave_min_i32(best == m ? idx : 0x7fffffff);
+          const float first = read_lane(o.v[0], 0);
+          if (lane == 0) disp_all[(size_t)b * npix + (size_t)q] = (first != first) ? 0 : win;
+        }
       }
     }
   }
+}
+
+// The same repeated adds, one wave per pixel of the diagonal, followed by the pixel's
+// winner-takes-all (fused aggregation + reduction on wide images).  store_sum = 0 leaves
+// the sum volume untouched.
+__global__ __launch_bounds__(64) void sgm_repeat_wta_kernel(float *__restrict__ out_all,
+                                                            const float *__restrict__ ws_all,
+                                                            int32_t *__restrict__ disp_all,
+                                                            const SgmRepeat R, int store_sum) {
+  const int lane = threadIdx.x;
+  const int i = blockIdx.x;
+  const int b = blockIdx.y;
+  const long pix = (long)(R.y0 + i * R.dy) * R.W + (R.x0 + i * R.dx);
+  float *o = out_all + ((size_t)b * R.H * R.W + (size_t)pix) * R.D;
+  const float *l = ws_all + ((size_t)b * R.ws_rows + i) * R.D;
+  float best = __builtin_inff();
+  int idx = 0x7fffffff;
+  float first = 0.0f;
+  for (int d = lane; d < R.D; d += 64) {
+    float acc = o[d];
+    const float lv = l[d];
+    for (int r = 0; r < R.count; ++r) acc = acc + lv;
+    if (store_sum) o[d] = acc;
+    if (d == 0) first = acc;
+    if (idx == 0x7fffffff) idx = d;
+    if (acc < best) { best = acc; idx = d; }
+  }
+  const float m = wave_min_f32(best);
+  const int win = wave_min_i32(best == m ? idx : 0x7fffffff);
+  first = read_lane(first, 0);
+  if (lane == 0) disp_all[(size_t)b * R.H * R.W + (size_t)pix] = (first != first) ? 0 : win;
 }
 
 template <int VPL>
@@ -587,6 +638,17 @@ int launch_repeat(float *out, const float *ws, int H, int W, int D, int batch, i
   hipLaunchKernelGGL(sgm_repeat_kernel, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, s,
                      out, ws, R);
   return check_launch("stm_sgm_f32 (repeat)");
+}
+
+int launch_repeat_wta(float *out, const float *ws, int32_t *disp, int H, int W, int D, int batch,
+                      int ws_rows, int x0, int y0, int dx, int dy, int len, int count,
+                      int store_sum, hipStream_t s) {
+  SgmRepeat R;
+  R.H = H; R.W = W; R.D = D; R.batch = batch; R.ws_rows = ws_rows;
+  R.x0 = x0; R.y0 = y0; R.dx = dx; R.dy = dy; R.len = len; R.count = count;
+  hipLaunchKernelGGL(sgm_repeat_wta_kernel, dim3(len, batch), dim3(64), 0, s, out, ws, disp, R,
+                     store_sum);
+  return check_launch("stm_sgm_wta_f32 (repeat)");
 }
 
 }  // namespace
@@ -651,27 +713,32 @@ int launch_ckpt(const float *cost, const float *image, float *ws, const PairShap
 }
 
 template <int VPL>
-int launch_pair(const float *cost, const float *image, float *out, float *ws, const PairShape &P,
-                bool vec, bool first, hipStream_t s) {
+int launch_pair(const float *cost, const float *image, float *out, float *ws, int32_t *disp,
+                const PairShape &P, bool vec, bool first, int final_mode, hipStream_t s) {
   const long waves = (long)P.paths[P.pair] * P.batch;
   const dim3 grid((unsigned)((waves + kSgmBlock / kWave - 1) / (kSgmBlock / kWave))), block(kSgmBlock);
-  if (vec && first)
-    hipLaunchKernelGGL((sgm_pair_kernel<VPL, true, true>), grid, block, 0, s, cost, image, out, ws, P);
-  else if (vec)
-    hipLaunchKernelGGL((sgm_pair_kernel<VPL, true, false>), grid, block, 0, s, cost, image, out, ws, P);
-  else if (first)
-    hipLaunchKernelGGL((sgm_pair_kernel<VPL, false, true>), grid, block, 0, s, cost, image, out, ws, P);
-  else
-    hipLaunchKernelGGL((sgm_pair_kernel<VPL, false, false>), grid, block, 0, s, cost, image, out, ws, P);
+#define STM_PAIR(VEC_, FIRST_, FINAL_)                                                         \
+  hipLaunchKernelGGL((sgm_pair_kernel<VPL, VEC_, FIRST_, FINAL_>), grid, block, 0, s, cost, image, \
+                     out, ws, disp, P)
+  if (final_mode == 1) { if (vec) STM_PAIR(true, false, 1); else STM_PAIR(false, false, 1); }
+  else if (final_mode == 2) { if (vec) STM_PAIR(true, false, 2); else STM_PAIR(false, false, 2); }
+  else if (vec && first) STM_PAIR(true, true, 0);
+  else if (vec) STM_PAIR(true, false, 0);
+  else if (first) STM_PAIR(false, true, 0);
+  else STM_PAIR(false, false, 0);
+#undef STM_PAIR
   return check_launch("stm_sgm_f32 (pair)");
 }
 
 }  // namespace
 }  // namespace stm
 
-extern "C" int stm_sgm_f32(const float *cost, const float *left, float *out, int H, int W,
-                           int D, float penalty1, float penalty2, int flags, void *workspace,
-                           size_t workspace_bytes, int batch, void *stream) {
+// final_mode: 0 = aggregation only; 1 = aggregation + fused winner-takes-all; 2 = fused
+// winner-takes-all without writing the finished sum (out then holds the first six
+// directions' sum).
+static int sgm_run(const float *cost, const float *left, float *out, int32_t *disp, int H, int W,
+                   int D, float penalty1, float penalty2, int flags, void *workspace,
+                   size_t workspace_bytes, int batch, void *stream, int final_mode) {
   using namespace stm;
   STM_REQUIRE(cost && left && out, STM_EINVAL, "stm_sgm_f32: null pointer");
   STM_REQUIRE(H > 0 && W > 0 && D > 0 && batch > 0, STM_EINVAL,
@@ -685,6 +752,8 @@ extern "C" int stm_sgm_f32(const float *cost, const float *left, float *out, int
   STM_REQUIRE((long long)batch * (W + H) < (1ll << 28) && batch <= 65535, STM_EUNSUPPORTED,
               "stm_sgm_f32: too many paths in one launch");
   const bool paired = !(flags & STM_SGM_SINGLE_PASSES);
+  STM_REQUIRE(final_mode == 0 || (paired && disp), STM_EINVAL,
+              "stm_sgm_wta_f32: needs a disparity pointer and the paired form");
   SgmPlan plan = sgm_plan(H, W, D, batch, paired);
   const size_t need = plan.total_floats * sizeof(float);
   STM_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), STM_EWORKSPACE,
@@ -715,23 +784,29 @@ extern "C" int stm_sgm_f32(const float *cost, const float *left, float *out, int
     for (int pair = 0; pair < 4; ++pair) {
       P.pair = pair;
       const bool first = pair == 0 && !accumulate;
+      // The fused reduction belongs to the last pair; on wide images the re-walked
+      // anti-diagonal still receives adds afterwards and is reduced by the repeat kernel.
+      const int fm = pair == 3 ? final_mode : 0;
       // Tall images: the corner diagonal's early re-walks precede the (1,1) forward pass.
       if (pair == 2 && quirk.tall_extra > 0) {
         rc = launch_repeat(out, ws, H, W, D, batch, P.ws_rows, W - 1, H - 1, -1, -1, W, quirk.tall_extra, s);
         if (rc != STM_OK) return rc;
       }
       switch (VPL) {
-        case 1: rc = launch_pair<1>(cost, left, out, ws, P, vec, first, s); break;
-        case 2: rc = launch_pair<2>(cost, left, out, ws, P, vec, first, s); break;
-        case 4: rc = launch_pair<4>(cost, left, out, ws, P, vec, first, s); break;
-        case 8: rc = launch_pair<8>(cost, left, out, ws, P, vec, first, s); break;
-        default: rc = launch_pair<16>(cost, left, out, ws, P, vec, first, s); break;
+        case 1: rc = launch_pair<1>(cost, left, out, ws, disp, P, vec, first, fm, s); break;
+        case 2: rc = launch_pair<2>(cost, left, out, ws, disp, P, vec, first, fm, s); break;
+        case 4: rc = launch_pair<4>(cost, left, out, ws, disp, P, vec, first, fm, s); break;
+        case 8: rc = launch_pair<8>(cost, left, out, ws, disp, P, vec, first, fm, s); break;
+        default: rc = launch_pair<16>(cost, left, out, ws, disp, P, vec, first, fm, s); break;
       }
       if (rc != STM_OK) return rc;
       if (pair == 2 && quirk.wide_extra > 0)
         rc = launch_repeat(out, ws, H, W, D, batch, P.ws_rows, W - 1, H - 1, -1, -1, H, quirk.wide_extra, s);
-      else if (pair == 3 && quirk.wide_extra > 0)
+      else if (pair == 3 && quirk.wide_extra > 0 && final_mode == 0)
         rc = launch_repeat(out, ws, H, W, D, batch, P.ws_rows, 0, H - 1, 1, -1, H, quirk.wide_extra, s);
+      else if (pair == 3 && quirk.wide_extra > 0)
+        rc = launch_repeat_wta(out, ws, disp, H, W, D, batch, P.ws_rows, 0, H - 1, 1, -1, H,
+                               quirk.wide_extra, final_mode == 1 ? 1 : 0, s);
       if (rc != STM_OK) return rc;
     }
     return STM_OK;
@@ -762,4 +837,22 @@ extern "C" int stm_sgm_f32(const float *cost, const float *left, float *out, int
     if (rc != STM_OK) return rc;
   }
   return STM_OK;
+}
+
+extern "C" int stm_sgm_f32(const float *cost, const float *left, float *out, int H, int W,
+                           int D, float penalty1, float penalty2, int flags, void *workspace,
+                           size_t workspace_bytes, int batch, void *stream) {
+  return sgm_run(cost, left, out, nullptr, H, W, D, penalty1, penalty2, flags, workspace,
+                 workspace_bytes, batch, stream, 0);
+}
+
+extern "C" int stm_sgm_wta_f32(const float *cost, const float *left, float *sum,
+                               int32_t *disparity, int H, int W, int D, float penalty1,
+                               float penalty2, int flags, void *workspace, size_t workspace_bytes,
+                               int batch, void *stream) {
+  STM_REQUIRE(disparity, STM_EINVAL, "stm_sgm_wta_f32: null disparity pointer");
+  STM_REQUIRE(!(flags & STM_SGM_SINGLE_PASSES), STM_EINVAL,
+              "stm_sgm_wta_f32: the fused reduction exists in the paired form only");
+  return sgm_run(cost, left, sum, disparity, H, W, D, penalty1, penalty2, flags, workspace,
+                 workspace_bytes, batch, stream, (flags & STM_SGM_KEEP_SUM) ? 1 : 2);
 }

@@ -17,6 +17,7 @@ ABI_VERSION = 1
 STM_SSD_MODES = {"auto": 0, "ordered": 1, "box": 2}
 STM_SGM_ACCUMULATE = 1
 STM_SGM_SINGLE_PASSES = 2
+STM_SGM_KEEP_SUM = 4
 STM_DP_MODES = {"reference": 0, "corrected": 1}
 
 # name -> (restype, argtypes); every symbol include/stereomatch_hip.h declares.
@@ -29,6 +30,7 @@ PROTOTYPES = {
     "stm_birchfield_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "stm_sgm_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "stm_sgm_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _sz, _i, _vp]),
+    "stm_sgm_wta_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _sz, _i, _vp]),
     "stm_wta_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "stm_dp_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
 }

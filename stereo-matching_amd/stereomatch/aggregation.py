@@ -31,6 +31,25 @@ class Semiglobal:
 
     def __call__(self, cost_volume: torch.Tensor, left_image: torch.Tensor,
                  sga_volume: Optional[torch.Tensor] = None) -> torch.Tensor:
+        sga_volume, _ = self._run(cost_volume, left_image, sga_volume, None, fused=False)
+        return sga_volume
+
+    def aggregate_and_reduce(self, cost_volume: torch.Tensor, left_image: torch.Tensor,
+                             sga_volume: Optional[torch.Tensor] = None,
+                             disparity_img: Optional[torch.Tensor] = None,
+                             keep_sum: bool = False):
+        """Aggregation and winner-takes-all in one call (``stm_sgm_wta_f32``): the last
+        direction pair reduces each finished row while it is in registers.  Returns
+        ``(volume, disparity)``; the disparity equals ``WinnerTakesAll()(self(cost, left))``
+        bit for bit.  Unless ``keep_sum`` the returned volume is scratch (it holds the sum of
+        the first six directions)."""
+        if self.single_passes:
+            raise RuntimeError("Semiglobal.aggregate_and_reduce needs the paired form "
+                               "(single_passes=False)")
+        return self._run(cost_volume, left_image, sga_volume, disparity_img, fused=True,
+                         keep_sum=keep_sum)
+
+    def _run(self, cost_volume, left_image, sga_volume, disparity_img, fused, keep_sum=False):
         _native.require_gpu(cost_volume, left_image)
         if cost_volume.dtype != torch.float32:
             raise RuntimeError("SemiglobalCPU: float32 cost volumes only on this device path")
@@ -46,14 +65,26 @@ class Semiglobal:
         image = left_image.float().contiguous()
         lib = _native.lib()
         flags = _native.STM_SGM_SINGLE_PASSES if self.single_passes else 0
+        if fused:
+            disparity_img = output_tensor(cost_volume.shape[:-1], torch.int32, device,
+                                          reuse=disparity_img)
+            if keep_sum:
+                flags |= _native.STM_SGM_KEEP_SUM
         ws_bytes = lib.stm_sgm_workspace_bytes(height, width, max_disparity, batch, flags)
         if ws_bytes and (self._workspace is None or self._workspace.device != device
                          or self._workspace.numel() < ws_bytes):
             self._workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
         ws_ptr = self._workspace.data_ptr() if (ws_bytes and self._workspace is not None) else None
         with torch.cuda.device(device):
-            _native.check(lib.stm_sgm_f32(
-                cost.data_ptr(), image.data_ptr(), sga_volume.data_ptr(), height, width,
-                max_disparity, float(self.penalty1), float(self.penalty2), flags, ws_ptr, ws_bytes,
-                batch, _native.stream_ptr(device)))
-        return sga_volume
+            if fused:
+                _native.check(lib.stm_sgm_wta_f32(
+                    cost.data_ptr(), image.data_ptr(), sga_volume.data_ptr(),
+                    disparity_img.data_ptr(), height, width, max_disparity, float(self.penalty1),
+                    float(self.penalty2), flags, ws_ptr, ws_bytes, batch,
+                    _native.stream_ptr(device)))
+            else:
+                _native.check(lib.stm_sgm_f32(
+                    cost.data_ptr(), image.data_ptr(), sga_volume.data_ptr(), height, width,
+                    max_disparity, float(self.penalty1), float(self.penalty2), flags, ws_ptr,
+                    ws_bytes, batch, _native.stream_ptr(device)))
+        return sga_volume, disparity_img

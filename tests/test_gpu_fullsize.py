@@ -42,6 +42,11 @@ def test_pipeline_reproduces_reference_digests(device, oracle, case, mode):
     full = stereomatch.Pipeline(stereomatch.cost.SSD(D, mode=mode),
                                 stereomatch.disparity_reduce.WinnerTakesAll(),
                                 stereomatch.aggregation.Semiglobal())
+    fused = stereomatch.Pipeline(stereomatch.cost.SSD(D, mode=mode),
+                                 stereomatch.disparity_reduce.WinnerTakesAll(),
+                                 stereomatch.aggregation.Semiglobal())
+    full.fuse = False
+    assert digest16(fused.estimate(Lg, Rg)) == g["ssd_sgm_wta"], "fused SGM+WTA"
     for attempt in range(2):
         d1 = plain.estimate(Lg, Rg)
         assert digest16(plain._cost_volume) == g["ssd"], "SSD volume (attempt %d)" % attempt
@@ -108,6 +113,8 @@ def test_1080p_sgm_full_volume_matches_oracle(device, oracle):
     assert torch.equal(S.view(torch.int32), S1.view(torch.int32))   # paired == eight passes
     del S1
     disp = stereomatch.disparity_reduce.WinnerTakesAll()(S)
+    _, fused_disp = stereomatch.aggregation.Semiglobal().aggregate_and_reduce(C, Lg)
+    assert torch.equal(fused_disp, disp)                            # fused reduction == separate
     Ch = C.cpu().numpy()
     del C
     want = oracle.sgm(Ch, L, 0.1, 0.2)

@@ -297,3 +297,38 @@ def test_gpu_matches_committed_golden_vectors(device, name):
     if "dp" in z.files:
         dpr = stereomatch.disparity_reduce.DynamicProgramming()(S)
         assert_same_bits(dpr.cpu().numpy(), z["dp"], "golden dp")
+
+
+# ------------------------------------------------------ fused aggregation + reduction
+@pytest.mark.parametrize("H,W,D", [(24, 40, 16), (40, 24, 16), (30, 30, 64), (20, 70, 128),
+                                    (70, 20, 128), (12, 40, 256), (9, 11, 100), (31, 30, 64)])
+@pytest.mark.parametrize("keep_sum", [False, True])
+def test_fused_sgm_wta_equals_separate_calls(device, oracle, H, W, D, keep_sum):
+    import stereomatch
+    rng = np.random.default_rng(H + W + D)
+    C = _random_volume(rng, H, W, D, "ties")   # plenty of exact ties for the index rule
+    image = rng.integers(0, 6, size=(H, W)).astype(np.float32)
+    want_S = oracle.sgm(C, image, 0.1, 0.2)
+    want_d = oracle.wta(want_S)
+    sgm = stereomatch.aggregation.Semiglobal()
+    vol, disp = sgm.aggregate_and_reduce(_gpu(C, device), _gpu(image, device), keep_sum=keep_sum)
+    assert_same_bits(disp.cpu().numpy(), want_d, "fused disparity")
+    if keep_sum:
+        assert_same_bits(vol.cpu().numpy(), want_S, "fused kept sum")
+
+
+def test_pipeline_fuses_by_default_and_matches_unfused(device, oracle):
+    import stereomatch
+    L, R = oracle.synthetic_pair(40, 64, seed=9)
+    Lg, Rg = _gpu(L, device), _gpu(R, device)
+    mk = lambda fuse: stereomatch.Pipeline(stereomatch.cost.SSD(32),
+                                           stereomatch.disparity_reduce.WinnerTakesAll(),
+                                           stereomatch.aggregation.Semiglobal(), fuse=fuse)
+    a, b = mk(True), mk(False)
+    da, db = a.estimate(Lg, Rg), b.estimate(Lg, Rg)
+    assert torch.equal(da, db)
+    assert_same_bits(db.cpu().numpy(), oracle.wta(oracle.sgm(oracle.ssd(L, R, 32), L)), "pipeline")
+    assert a.estimate(Lg, Rg) is da      # buffers are reused in the fused path too
+    with pytest.raises(RuntimeError):    # the reducer's power-of-two rule still applies
+        stereomatch.Pipeline(stereomatch.cost.SSD(24), stereomatch.disparity_reduce.WinnerTakesAll(),
+                             stereomatch.aggregation.Semiglobal()).estimate(Lg, Rg)
