@@ -58,30 +58,42 @@ def main():
             f.write("%s,%d,%.1f,%.1f,%.1f\n" % (k[0].replace(",", ";"), k[1], fr, 2 * fr,
                                                  counters["WRITE_SIZE"].get(k, 0.0)))
 
-    # HBM bytes per aggregation: the SGM launches of one bench step, identified by VPL
-    # (sgm_pass_kernel<2,...> = Teddy D=128, <4,...> = 1080p D=256), summed over one step.
+    # HBM bytes per aggregation: dispatches in order, one group per sgm_ckpt_kernel launch
+    # (ckpt + 4 pair launches + repeat kernels); groups whose last pair kernel is the fused
+    # disparity-only variant (template argument FINAL = 2) are the ones bench.py times.
     def per_step(vpl):
-        fetch = write = 0.0
-        steps = None
+        out = {}
         for name, d, scale in (("FETCH_SIZE", fetch_dir, 2.0), ("WRITE_SIZE", write_dir, 1.0)):
             rows = [r for r in load(os.path.join(d, prefix + "_counter_collection.csv"))
-                    if r["Counter_Name"] == name and ("sgm_" in r["Kernel_Name"])]
-            mine = [r for r in rows if ("sgm_pass_kernel<%d," % vpl) in r["Kernel_Name"]]
-            firsts = sum(1 for r in mine if short(r["Kernel_Name"]).endswith(", true>"))
-            steps = max(firsts, 1)
-            tot = sum(float(r["Counter_Value"]) for r in mine) * 1024.0 * scale / steps
-            if name == "FETCH_SIZE":
-                fetch = tot
-            else:
-                write = tot
-        return fetch + write, fetch, write
+                    if r["Counter_Name"] == name and "sgm_" in r["Kernel_Name"]]
+            rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+            groups, cur = [], None
+            for r in rows:
+                k = short(r["Kernel_Name"])
+                if k.startswith("sgm_ckpt_kernel"):
+                    cur = {"vpl": k, "bytes": 0.0, "fused": False}
+                    groups.append(cur)
+                if cur is None:
+                    continue
+                cur["bytes"] += float(r["Counter_Value"]) * 1024.0 * scale
+                if k.startswith("sgm_pair_kernel") and k.endswith(", 2>"):
+                    cur["fused"] = True
+            mine = [g for g in groups if g["vpl"].startswith("sgm_ckpt_kernel<%d," % vpl)]
+            for kind in (True, False):
+                sel = [g["bytes"] for g in mine if g["fused"] == kind]
+                out[(name, kind)] = sum(sel) / len(sel) if sel else 0.0
+        return out
     traffic = {}
     for wl, vpl in (("teddy", 2), ("1080p", 4)):
-        tot, fe, wr = per_step(vpl)
-        traffic[wl] = round(tot)
-        traffic[wl + "_detail"] = {"fetch_bytes_corrected": round(fe), "write_bytes": round(wr)}
-    traffic["_note"] = ("HBM bytes per semiglobal aggregation of one bench step (Teddy: 16 pairs, "
-                        "1080p: 2 pairs), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; "
+        o = per_step(vpl)
+        traffic[wl] = round(o[("FETCH_SIZE", True)] + o[("WRITE_SIZE", True)])
+        traffic[wl + "_detail"] = {
+            "fused_fetch_bytes_corrected": round(o[("FETCH_SIZE", True)]),
+            "fused_write_bytes": round(o[("WRITE_SIZE", True)]),
+            "unfused_fetch_bytes_corrected": round(o[("FETCH_SIZE", False)]),
+            "unfused_write_bytes": round(o[("WRITE_SIZE", False)])}
+    traffic["_note"] = ("HBM bytes per fused aggregation+WTA of one bench step (Teddy: 16 pairs, "
+                        "1080p: 4 pairs), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; "
                         "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128 B request); "
                         "tag " + tag)
     with open(os.path.join(HERE, "traffic.json"), "w") as f:
