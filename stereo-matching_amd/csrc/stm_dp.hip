@@ -22,7 +22,9 @@
 //         reference leaves it to torch.empty; its pinned form zero-fills).
 //
 // The in-place d loop is a serial (min,+) chain with a rounded add at every link, so a
-// scan would re-associate the adds.  It is parallelised exactly instead: with
+// scan would re-associate the adds.  Two exact parallelisations are used: the skewed
+// wavefront of dp_tile_kernel (the fast path, below) and, for disparity counts it does not
+// cover, a fixed-point iteration (dp_forward_kernel): with
 // m23[d] = (c2 < c3 ? c2 : c3) the update is new[d] = cost[d] + (new[d-1] < m23[d] ?
 // new[d-1] : m23[d]); starting from new[d] = cost[d] + m23[d] and re-applying that map
 // until nothing changes reaches the chain's unique fixed point with the very same
@@ -31,8 +33,9 @@
 // the lower neighbour's new cost undercuts both old costs), so a column costs a few
 // wave-parallel sweeps instead of D dependent steps.
 //
-// Design: one wave per image row; lane l holds disparities l*VPL .. l*VPL+VPL-1.
-// Bound: HBM, 4 bytes read + 1 byte written per (pixel, d) in the forward pass.
+// dp_forward_kernel: one wave per image row; lane l holds disparities l*VPL .. l*VPL+VPL-1.
+// Bound: HBM by bytes (4 read + 1 written per (pixel, d)); in practice the forward pass is
+// latency-bound by its dependent chain.
 #include "stm_common.h"
 
 namespace stm {
@@ -159,6 +162,172 @@ __global__ __launch_bounds__(kDpBlock) void dp_forward_kernel(const float *__res
     if (d0 + j < D) rowfin[d0 + j] = prev[j];
 }
 
+// ---------------------------------------------------------------------------------
+// Forward pass, skewed-wavefront form (the fast path; D a multiple of O, see the host code).
+//
+// Element (col, d) of a row depends on (col, d-1) [the in-place update], (col-1, d) and
+// (col-1, d+1).  With the schedule t = O*col + d (O >= 2) all three are finished before step
+// t, so the elements {(col, t - O*col)} are independent: a lane follows one column down the
+// disparity axis -- its previous output stays in a register -- O steps behind the lane of
+// the column to its left, whose outputs arrive through one DPP row rotation per step and
+// wait in an O-deep register ring until they are (col-1, d) and (col-1, d+1).  This
+// evaluates exactly the reference's serial recurrence (no re-association, no speculation)
+// in O*(W-1) + D steps per row instead of W*D.
+//
+// Geometry: a DPP row of 16 lanes owns one image row, so a wave advances four image rows;
+// P = 16*O >= D is the period a lane spends on a column, after which it continues with the
+// column 16 to the right, i.e. the pipeline is filled once per row.  Time is cut in blocks
+// of O steps: in block `blk` lane v works on the O-aligned chunk m = (blk - v) mod 16 of its
+// column, so each lane needs exactly one aligned 4*O-byte piece of the cost volume per
+// block.  The 64 pieces of the next block are fetched cooperatively as whole 4*O-byte runs
+// (16-byte loads, 4*O/16 lanes per piece -- a lane-private stream would touch every cache
+// line 4 to 8 times), parked in registers during the block and dropped into a padded LDS
+// tile at its end; the path directions of a block leave as one O-byte store per lane.
+// ---------------------------------------------------------------------------------
+template <int O>
+__global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ vol_all,
+                                                     int8_t *__restrict__ path_all,
+                                                     float *__restrict__ rowfin_all,
+                                                     const DpShape S) {
+  constexpr int P = 16 * O;
+  constexpr int LP = O / 4;          // lanes per cost piece (16 bytes each)
+  constexpr int PPI = 64 / LP;       // pieces per cooperative load instruction
+  constexpr int LD = O + 1;          // padded LDS row: conflict-free ds_read_b32 by 64 lanes
+  __shared__ float tile[2][64 * LD];
+  __shared__ float init[4][P];
+  __shared__ float fin[4][P + 1];
+  const int lane = threadIdx.x;
+  const int rq = lane >> 4, v = lane & 15;
+  const int b = blockIdx.y;
+  const int D = S.D, W = S.W, H = S.H;
+  const int row = blockIdx.x * 4 + rq;
+  const bool rowok = row < H;
+  const size_t npix = (size_t)H * W;
+  const float *vol = vol_all + (size_t)b * npix * D;
+  int8_t *path = path_all + (size_t)b * npix * D;
+  const float inf = __builtin_inff();
+
+  // Column 0: previous-cost initialisation (Q11a: the reference reads cost[d][row][0]).
+  for (int d = v; d < D; d += 16) {
+    float x = 0.0f;
+    if (rowok) x = S.mode == STM_DP_REFERENCE ? vol[((size_t)d * W + row) * D] : vol[((size_t)row * W) * D + d];
+    init[rq][d] = x;
+  }
+
+  // Cooperative fetch of the cost pieces block `blk` will consume: instruction u, lane i
+  // serves piece pi = u*PPI + i/LP (the piece lane pi owns), 16-byte part i%LP.
+  auto fetch = [&](int blk, float4 (&regs)[LP]) {
+#pragma unroll
+    for (int u = 0; u < LP; ++u) {
+      const int pi = u * PPI + lane / LP, part = lane % LP;
+      const int prow = blockIdx.x * 4 + (pi >> 4), pv = pi & 15;
+      const int q = blk - pv;
+      const int pcol = pv + 16 * (q >> 4), pd0 = O * (q & 15);
+      const bool ok = q >= 0 && pcol < W && pd0 < D && prow < H;
+      const size_t at = ok ? ((size_t)prow * W + pcol) * D + pd0 + 4 * part : 0;
+      const float4 x = *reinterpret_cast<const float4 *>(vol + at);
+      regs[u] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto park = [&](int buf, const float4 (&regs)[LP]) {
+#pragma unroll
+    for (int u = 0; u < LP; ++u) {
+      const int pi = u * PPI + lane / LP, part = lane % LP;
+      float *dst = &tile[buf][pi * LD + 4 * part];
+      dst[0] = regs[u].x; dst[1] = regs[u].y; dst[2] = regs[u].z; dst[3] = regs[u].w;
+    }
+  };
+
+  float4 regs[LP];
+  fetch(0, regs);
+  park(0, regs);
+  float hist[O];
+#pragma unroll
+  for (int j = 0; j < O; ++j) hist[j] = inf;
+  float prev = inf;
+  const int nblocks = W + 15;
+  for (int blk = 0; blk < nblocks; ++blk) {
+    const int cur = blk & 1;
+    fetch(blk + 1, regs);  // in flight while this block computes
+    const int q = blk - v;
+    const int col = v + 16 * (q >> 4);
+    const int d0 = O * (q & 15);
+    const bool live = q >= 0 && col < W && d0 < D && rowok;
+    // The block's O cost values move from LDS to registers up front, so the dependent
+    // chain below has no memory waits.  Lanes without work get +inf costs, which makes
+    // their outputs +inf without a select in the chain.
+    float cst[O], outs[O];
+#pragma unroll
+    for (int j = 0; j < O; ++j) {
+      const float x = tile[cur][lane * LD + j];
+      cst[j] = live ? x : inf;
+    }
+    unsigned pk[LP];
+#pragma unroll
+    for (int u = 0; u < LP; ++u) pk[u] = 0;
+    const bool col0 = live && col == 0;
+    if (blk < 16) {
+      // Column 0 is in flight (wave-uniform test): its "update" is the initial cost with
+      // direction 0, so these blocks carry one extra select per step.
+#pragma unroll
+      for (int j = 0; j < O; ++j) {
+        const int d = d0 + j;
+        const float c2 = hist[j];                 // (col-1, d),   received O steps ago
+        const float c3 = d < D - 1 ? hist[(j + 1) % O] : inf;  // (col-1, d+1)
+        const float c1 = d > 0 ? prev : inf;
+        const float m23 = c2 < c3 ? c2 : c3;
+        const float m = c1 < m23 ? c1 : m23;
+        const float out = col0 ? init[rq][d < P ? d : 0] : cst[j] + m;
+        const int dir = col0 ? 0 : (c1 < m23 ? -1 : (c2 < c3 ? 0 : 1));
+        prev = out;
+        outs[j] = out;
+        pk[j / 4] |= (unsigned)(dir & 0xff) << (8 * (j % 4));
+        hist[j] = dpp_f32<0x121>(out, out);        // row_ror:1 -> the column on the right
+      }
+    } else {
+      // Steady state.  With m23 = (c2 < c3 ? c2 : c3) the reference's three-way choice is
+      // new = cost + min(c1, m23), direction -1 iff c1 < m23: the dependent chain per step
+      // is one v_min_f32 and one v_add_f32; m23 and the direction are off the chain.
+      float c1 = d0 > 0 ? prev : inf;
+#pragma unroll
+      for (int j = 0; j < O; ++j) {
+        const float c2 = hist[j];
+        const float c3 = d0 + j < D - 1 ? hist[(j + 1) % O] : inf;
+        const float m23 = c2 < c3 ? c2 : c3;
+        const float out = cst[j] + fminf(c1, m23);
+        const int dir = c1 < m23 ? -1 : (c2 < c3 ? 0 : 1);
+        outs[j] = out;
+        pk[j / 4] |= (unsigned)(dir & 0xff) << (8 * (j % 4));
+        hist[j] = dpp_f32<0x121>(out, out);
+        c1 = out;
+      }
+      prev = c1;
+    }
+    if (blk >= nblocks - 16) {  // wave-uniform: the last column is in flight
+      // Final costs of the row: the lane that owns the last column parks them in LDS.
+      const bool isfin = live && col == W - 1;
+#pragma unroll
+      for (int j = 0; j < O; ++j) fin[rq][isfin ? d0 + j : P] = outs[j];  // slot P: dump
+    }
+    if (live) {
+      int8_t *dst = path + ((size_t)row * W + col) * D + d0;
+#pragma unroll
+      for (int u = 0; u < LP; u += 4) {
+        if (LP >= 4) {
+          *reinterpret_cast<uint4 *>(dst + 4 * u) = make_uint4(pk[u], pk[(u + 1) % LP], pk[(u + 2) % LP], pk[(u + 3) % LP]);
+        } else {
+          *reinterpret_cast<uint2 *>(dst) = make_uint2(pk[0], pk[1 % LP]);
+        }
+      }
+    }
+    park(cur ^ 1, regs);
+  }
+  // Flush the final costs.
+  float *rowfin = rowfin_all + ((size_t)b * H + (rowok ? row : 0)) * D;
+  if (rowok)
+    for (int d = v; d < D; d += 16) rowfin[d] = fin[rq][d];
+}
+
 // Q11b: path[r][c][0] = 0 for r < D, r < c < H (and c < W, implied by H <= W).
 __global__ void dp_clobber_kernel(int8_t *__restrict__ path_all, const DpShape S) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -261,6 +430,19 @@ extern "C" int stm_dp_f32(const float *volume, int8_t *path, float *row_final, i
   const uintptr_t align = VPL >= 4 ? 15 : (VPL == 2 ? 7 : 3);
   const bool vec = (D == VPL * 64) && ((reinterpret_cast<uintptr_t>(volume) & align) == 0) &&
                    ((reinterpret_cast<uintptr_t>(path) & 3) == 0);
+  // Wavefront form: whole O-disparity chunks (O = 8, 16, 32, 64 for D <= 128, 256, 512, 1024)
+  // and 16-byte-aligned cost rows; everything else takes the fixed-point form.
+  int O = 8;
+  while (16 * O < D) O <<= 1;
+  const bool wavefront = (D % O == 0) && ((reinterpret_cast<uintptr_t>(volume) & 15) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(path) & 15) == 0);
+  if (wavefront) {
+    const dim3 wgrid((H + 3) / 4, batch), wblock(64);
+    if (O == 8) hipLaunchKernelGGL(dp_tile_kernel<8>, wgrid, wblock, 0, s, volume, path, row_final, S);
+    else if (O == 16) hipLaunchKernelGGL(dp_tile_kernel<16>, wgrid, wblock, 0, s, volume, path, row_final, S);
+    else if (O == 32) hipLaunchKernelGGL(dp_tile_kernel<32>, wgrid, wblock, 0, s, volume, path, row_final, S);
+    else hipLaunchKernelGGL(dp_tile_kernel<64>, wgrid, wblock, 0, s, volume, path, row_final, S);
+  } else {
 #define STM_DP_LAUNCH(V)                                                                              \
   do {                                                                                                \
     if (vec) hipLaunchKernelGGL((dp_forward_kernel<V, true>), grid, block, 0, s, volume, path, row_final, S); \
@@ -274,6 +456,7 @@ extern "C" int stm_dp_f32(const float *volume, int8_t *path, float *row_final, i
     default: STM_DP_LAUNCH(16); break;
   }
 #undef STM_DP_LAUNCH
+  }
   int rc = check_launch("stm_dp_f32 (forward)");
   if (rc != STM_OK) return rc;
   if (mode == STM_DP_REFERENCE && H > 1) {

@@ -4,13 +4,14 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "stereo-matching
 import numpy as np, torch, stereomatch
 from bench import synthetic_pair
 dev = torch.device("cuda:0")
-for H, W, D in ((375, 450, 128), (1080, 1920, 256)):
-    Ln, Rn = synthetic_pair(H, W, 0)
-    L = torch.from_numpy(Ln).to(dev); R = torch.from_numpy(Rn).to(dev)
+for H, W, D, B in ((375, 450, 128, 1), (375, 450, 128, 16), (1080, 1920, 256, 1), (1080, 1920, 256, 2)):
+    pairs = [synthetic_pair(H, W, s) for s in range(B)]
+    L = torch.from_numpy(np.stack([p[0] for p in pairs])).to(dev)
+    R = torch.from_numpy(np.stack([p[1] for p in pairs])).to(dev)
     C = stereomatch.cost.Birchfield(D)(L, R)
     S = stereomatch.aggregation.Semiglobal()(C, L)
     dp = stereomatch.disparity_reduce.DynamicProgramming()
-    for _ in range(3):
+    for _ in range(2):
         d = dp(S)
     torch.cuda.synchronize()
-    print(H, W, D, float((d == 7).float().mean()))
+    print(H, W, D, B, float((d == 7).float().mean()))
