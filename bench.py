@@ -207,6 +207,31 @@ def cpu_baseline(budget_s=20.0):
                          stages[2] / done)}
 
 
+def config3_line(device, steps, batch=16):
+    """BASELINE config 3: Teddy 450x375, Birchfield + SGM + dynamic-programming reduce, D=128
+    (reported beside the primary workload; parity gate: the reference's DP digest)."""
+    import stereomatch
+    H, W, D = 375, 450, 128
+    pairs = [synthetic_pair(H, W, seed=b) for b in range(batch)]
+    left = torch.from_numpy(np.stack([p[0] for p in pairs])).to(device)
+    right = torch.from_numpy(np.stack([p[1] for p in pairs])).to(device)
+    pipe = stereomatch.Pipeline(stereomatch.cost.Birchfield(D),
+                                stereomatch.disparity_reduce.DynamicProgramming(),
+                                stereomatch.aggregation.Semiglobal())
+    disp = pipe.estimate(left, right)
+    torch.cuda.synchronize()
+    assert digest16(disp[0].cpu().numpy()) == "0922d012b07edd03", "config 3 parity gate failed"
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.estimate(left, right)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"workload": "Teddy 450x375, Birchfield + SGM + dynamic-programming reduce, D=128",
+            "value": round(batch * steps / dt, 2), "unit": "pairs/s", "pairs_per_step": batch,
+            "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,6 +243,7 @@ def main():
     ap.add_argument("--also-steps", type=int, default=5)
     ap.add_argument("--also-batch", type=int, default=0, help="pairs per step of the second workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config3", action="store_true", help="skip the Birchfield+SGM+DP extra line")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -279,6 +305,9 @@ def main():
         }
         del job2
         torch.cuda.empty_cache()
+
+    if world == 1 and not args.no_config3:
+        out["also_config3"] = config3_line(device, args.also_steps)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()

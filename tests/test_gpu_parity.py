@@ -332,3 +332,62 @@ def test_pipeline_fuses_by_default_and_matches_unfused(device, oracle):
     with pytest.raises(RuntimeError):    # the reducer's power-of-two rule still applies
         stereomatch.Pipeline(stereomatch.cost.SSD(24), stereomatch.disparity_reduce.WinnerTakesAll(),
                              stereomatch.aggregation.Semiglobal()).estimate(Lg, Rg)
+
+
+# --------------------------------------------- stream ordering and graph capture
+def _pipeline_ops(D):
+    import stereomatch
+    return (stereomatch.cost.SSD(D), stereomatch.cost.Birchfield(D),
+            stereomatch.aggregation.Semiglobal(), stereomatch.disparity_reduce.WinnerTakesAll(),
+            stereomatch.disparity_reduce.DynamicProgramming(mode="corrected"))
+
+
+def test_ops_run_on_the_current_stream(device, oracle):
+    """The library launches on the stream it is handed (torch's current stream), not on
+    the legacy default stream like the reference."""
+    import stereomatch
+    L, R = oracle.synthetic_pair(30, 44, seed=5)
+    side = torch.cuda.Stream(device=device)
+    Lg, Rg = _gpu(L, device), _gpu(R, device)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        pipe = stereomatch.Pipeline(stereomatch.cost.SSD(32), stereomatch.disparity_reduce.WinnerTakesAll(),
+                                    stereomatch.aggregation.Semiglobal())
+        disp = pipe.estimate(Lg, Rg)
+    side.synchronize()
+    assert_same_bits(disp.cpu().numpy(), oracle.wta(oracle.sgm(oracle.ssd(L, R, 32), L)), "side stream")
+
+
+def test_pipeline_can_be_captured_into_a_graph(device, oracle):
+    """No entry point allocates, copies or synchronises, so a whole estimate() can be
+    captured once and replayed on new inputs (include/stereomatch_hip.h, conventions)."""
+    import stereomatch
+    H, W, D = 36, 52, 64
+    pairs = [oracle.synthetic_pair(H, W, seed=s) for s in (1, 2)]
+    Lg, Rg = _gpu(pairs[0][0], device), _gpu(pairs[0][1], device)
+    pipe = stereomatch.Pipeline(stereomatch.cost.SSD(D), stereomatch.disparity_reduce.WinnerTakesAll(),
+                                stereomatch.aggregation.Semiglobal())
+    pipe.estimate(Lg, Rg)                       # allocates the three buffers and workspaces
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = pipe.estimate(Lg, Rg)
+    for L, R in pairs[::-1]:
+        Lg.copy_(_gpu(L, device))
+        Rg.copy_(_gpu(R, device))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert_same_bits(out.cpu().numpy(), oracle.wta(oracle.sgm(oracle.ssd(L, R, D), L)), "graph replay")
+
+
+def test_non_contiguous_inputs_are_accepted(device, oracle):
+    """The reference honours strides through accessors; the wrappers make a contiguous copy."""
+    import stereomatch
+    L, R = oracle.synthetic_pair(20, 64, seed=8)
+    wide = _gpu(np.concatenate([L, R], axis=1), device)
+    Lv, Rv = wide[:, :64], wide[:, 64:]
+    assert not Lv.is_contiguous()
+    C = stereomatch.cost.SSD(16, kernel_size=3)(Lv, Rv)
+    assert_same_bits(C.cpu().numpy(), oracle.ssd(L, R, 16, 3), "strided ssd")
+    S = stereomatch.aggregation.Semiglobal()(C, Lv)
+    assert_same_bits(S.cpu().numpy(), oracle.sgm(oracle.ssd(L, R, 16, 3), L), "strided sgm")
