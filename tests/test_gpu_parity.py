@@ -391,3 +391,30 @@ def test_non_contiguous_inputs_are_accepted(device, oracle):
     assert_same_bits(C.cpu().numpy(), oracle.ssd(L, R, 16, 3), "strided ssd")
     S = stereomatch.aggregation.Semiglobal()(C, Lv)
     assert_same_bits(S.cpu().numpy(), oracle.sgm(oracle.ssd(L, R, 16, 3), L), "strided sgm")
+
+
+# --------------------------------------------------------------- degenerate shapes
+@pytest.mark.parametrize("H,W,D", [(1, 1, 64), (1, 1, 4), (5, 7, 64), (3, 70, 128), (2, 3, 256),
+                                    (65, 2, 64), (4, 130, 192)])
+def test_degenerate_shapes_full_chain(device, oracle, H, W, D):
+    """Images narrower than the window or the disparity range, single pixels, D that is a
+    multiple of 64 but not a power of two."""
+    import stereomatch
+    L, R = oracle.synthetic_pair(H, W, seed=H * W + D)
+    Lg, Rg = _gpu(L, device), _gpu(R, device)
+    for mode in ("auto", "ordered", "box"):
+        C = stereomatch.cost.SSD(D, mode=mode)(Lg, Rg)
+        assert_same_bits(C.cpu().numpy(), oracle.ssd(L, R, D, 7), "ssd " + mode)
+    Bt = stereomatch.cost.Birchfield(D)(Lg, Rg)
+    assert_same_bits(Bt.cpu().numpy(), oracle.birchfield(L, R, D), "birchfield")
+    Ch = oracle.ssd(L, R, D, 7)
+    for single in (False, True):
+        S = stereomatch.aggregation.Semiglobal(single_passes=single)(C, Lg)
+        assert_same_bits(S.cpu().numpy(), oracle.sgm(Ch, L), "sgm single=%s" % single)
+    Sh = oracle.sgm(Ch, L)
+    wta = stereomatch.disparity_reduce.WinnerTakesAll(require_power_of_two=False)
+    assert_same_bits(wta(S).cpu().numpy(), oracle.wta(Sh), "wta")
+    _, fused = stereomatch.aggregation.Semiglobal().aggregate_and_reduce(C, Lg)
+    assert_same_bits(fused.cpu().numpy(), oracle.wta(Sh), "fused wta")
+    dp = stereomatch.disparity_reduce.DynamicProgramming(mode="corrected")
+    assert_same_bits(dp(S).cpu().numpy(), oracle.dp(Sh, mode=1), "dp corrected")
