@@ -127,7 +127,14 @@ __device__ __forceinline__ void ssd_stage(const float *__restrict__ L, const flo
   __syncthreads();
 }
 
-// ORDERED body: every (column, 64-disparity chunk) item is one wave's job.
+// ORDERED body: a wave's job is a group of kOrdCB adjacent output columns x one
+// 64-disparity chunk.  The columns of a group share their window samples: per window row
+// the 2k + kOrdCB - 1 left samples are handed out by v_readlane from one register and the
+// same number of right samples are read from LDS once, then each column runs its own
+// 2k-tap sum in the reference's order (every output keeps its own dependent chain, so the
+// result is the ordered sum bit for bit; only the operand fetches are shared).
+constexpr int kOrdCB = 4;
+
 template <int K>  // K > 0: compile-time window half-size; K == 0: runtime S.k
 __device__ __forceinline__ void ssd_ordered_body(const SsdShape &S, int r, int c0,
                                                  const float *Ls, const float *Rs,
@@ -137,44 +144,121 @@ __device__ __forceinline__ void ssd_ordered_body(const SsdShape &S, int r, int c
   const int wave = wave_uniform(threadIdx.x >> 6);
   const int chunks = (S.D + 63) >> 6;
   const int cols = (S.W - c0) < kSsdTW ? (S.W - c0) : kSsdTW;
+  const int groups = (cols + kOrdCB - 1) / kOrdCB;
   const float inf = __builtin_inff();
-  for (int item = wave; item < cols * chunks; item += kSsdBlock / 64) {
-    const int ci = item / chunks, chunk = item - ci * chunks;
-    const int c = c0 + ci;
+  for (int item = wave; item < groups * chunks; item += kSsdBlock / 64) {
+    const int g = item / chunks, chunk = item - g * chunks;
+    const int ci0 = g * kOrdCB;
     const int d = chunk * 64 + lane;
-    // Column index of tap t: kc = c - k + t; staged left column = ci + t; staged
-    // right column of R[kc - d] = ci + t + (D - 1) - d.
-    const int rbase = ci + (S.D - 1) - d;
-    float s = 0.0f;
-    // Wave-uniform test: no lane's window is clipped on the left (kc >= d for
-    // all taps) or on the right (kc < W).
-    const bool interior = (c - k >= chunk * 64 + 63) && (c + k <= S.W);
+    const int ncol = cols - ci0 < kOrdCB ? cols - ci0 : kOrdCB;
+    // Wave-uniform test: no lane's window of any column of the group is clipped on the
+    // left (kc >= d for all taps) or on the right (kc < W).
+    const bool interior = ncol == kOrdCB && (c0 + ci0 - k >= chunk * 64 + 63) &&
+                          (c0 + ci0 + kOrdCB - 1 + k <= S.W);
     if (interior) {
+      // Tap t of column q: kc = c0 + ci0 + q - k + t; staged left column ci0 + q + t, staged
+      // right column of R[kc - d] = ci0 + q + t + (D - 1) - d.
+      const int rbase = ci0 + (S.D - 1) - d;
+      float s[kOrdCB];
 #pragma unroll
+      for (int q = 0; q < kOrdCB; ++q) s[q] = 0.0f;
+      // One window row per trip (not unrolled: 14 rows of hoisted operand loads would
+      // not fit the register file).
+#pragma unroll 1
       for (int j = 0; j < 2 * k; ++j) {
-        const float lrow = Ls[j * S.lw + ci + (lane < 2 * k ? lane : 0)];
+        const float lrow = Ls[j * S.lw + ci0 + (lane < 2 * k + kOrdCB - 1 ? lane : 0)];
         const float *rrow = Rs + j * S.rw + (rbase >= 0 ? rbase : 0);
+        if (K > 0) {
+          float rv[2 * (K > 0 ? K : 1) + kOrdCB - 1];
 #pragma unroll
-        for (int t = 0; t < 2 * k; ++t) {
-          const float diff = read_lane(lrow, t) - rrow[t];
-          const float sq = diff * diff;
-          s = s + sq;
+          for (int t = 0; t < 2 * k + kOrdCB - 1; ++t) rv[t] = rrow[t];
+#pragma unroll
+          for (int q = 0; q < kOrdCB; ++q) {
+#pragma unroll
+            for (int t = 0; t < 2 * k; ++t) {
+              const float diff = read_lane(lrow, q + t) - rv[q + t];
+              const float sq = diff * diff;
+              s[q] = s[q] + sq;
+            }
+          }
+        } else {
+          for (int q = 0; q < kOrdCB; ++q) {
+            for (int t = 0; t < 2 * k; ++t) {
+              const float diff = read_lane(lrow, q + t) - rrow[q + t];
+              const float sq = diff * diff;
+              s[q] = s[q] + sq;
+            }
+          }
         }
+      }
+      if (d < S.D) {
+#pragma unroll
+        for (int q = 0; q < kOrdCB; ++q)
+          C[((size_t)r * S.W + c0 + ci0 + q) * S.D + d] = s[q];  // d <= c holds for interior groups
+      }
+    } else if (K > 0 && chunk * 64 > c0 + ci0 + kOrdCB - 1) {
+      // Every disparity of the chunk exceeds every column of the group: all +inf.
+      if (d < S.D)
+        for (int q = 0; q < ncol; ++q) C[((size_t)r * S.W + c0 + ci0 + q) * S.D + d] = inf;
+    } else if (K > 0) {
+      // Clipped windows (left clip kc >= d, right image border): the same shared operand
+      // fetches, plus one lane mask per window column u = q + t (tap counts iff d <= kc < W);
+      // a masked-out tap adds nothing, which keeps the ordered sum intact.  Columns past the
+      // tile end are computed and dropped.
+      const int rbase = ci0 + (S.D - 1) - d;
+      float s[kOrdCB];
+#pragma unroll
+      for (int q = 0; q < kOrdCB; ++q) s[q] = 0.0f;
+      bool in[2 * (K > 0 ? K : 1) + kOrdCB - 1];
+#pragma unroll
+      for (int u = 0; u < 2 * k + kOrdCB - 1; ++u) {
+        const int kc = c0 + ci0 - k + u;
+        in[u] = d <= (kc < S.W ? kc : -1) && d < S.D;
+      }
+#pragma unroll 1
+      for (int j = 0; j < 2 * k; ++j) {
+        const int lcol = ci0 + (lane < 2 * k + kOrdCB - 1 ? lane : 0);
+        const float lrow = Ls[j * S.lw + (lcol < S.lw ? lcol : 0)];
+        const float *rrow = Rs + j * S.rw + (d < S.D ? rbase : 0);
+        float rv[2 * (K > 0 ? K : 1) + kOrdCB - 1];
+#pragma unroll
+        for (int u = 0; u < 2 * k + kOrdCB - 1; ++u)
+          rv[u] = rrow[ci0 + u < S.lw ? u : 0];
+#pragma unroll
+        for (int q = 0; q < kOrdCB; ++q) {
+#pragma unroll
+          for (int t = 0; t < 2 * k; ++t) {
+            const float diff = read_lane(lrow, q + t) - rv[q + t];
+            const float sq = diff * diff;
+            s[q] = in[q + t] ? s[q] + sq : s[q];
+          }
+        }
+      }
+      if (d < S.D) {
+#pragma unroll
+        for (int q = 0; q < kOrdCB; ++q)
+          if (q < ncol) C[((size_t)r * S.W + c0 + ci0 + q) * S.D + d] = d <= c0 + ci0 + q ? s[q] : inf;
       }
     } else {
-      for (int j = 0; j < 2 * k; ++j) {
-        const float lrow = Ls[j * S.lw + ci + (lane < 2 * k ? lane : 0)];
-        for (int t = 0; t < 2 * k; ++t) {
-          const int kc = c - k + t;
-          const bool in = (kc >= d) && (kc < S.W) && (d < S.D);
-          const float rv = Rs[j * S.rw + (in ? rbase + t : 0)];
-          const float diff = read_lane(lrow, t) - rv;
-          const float sq = diff * diff;
-          s = in ? s + sq : s;
+      for (int q = 0; q < ncol; ++q) {
+        const int ci = ci0 + q;
+        const int c = c0 + ci;
+        const int rbase = ci + (S.D - 1) - d;
+        float s = 0.0f;
+        for (int j = 0; j < 2 * k; ++j) {
+          const float lrow = Ls[j * S.lw + ci + (lane < 2 * k ? lane : 0)];
+          for (int t = 0; t < 2 * k; ++t) {
+            const int kc = c - k + t;
+            const bool in = (kc >= d) && (kc < S.W) && (d < S.D);
+            const float rv = Rs[j * S.rw + (in ? rbase + t : 0)];
+            const float diff = read_lane(lrow, t) - rv;
+            const float sq = diff * diff;
+            s = in ? s + sq : s;
+          }
         }
+        if (d < S.D) C[((size_t)r * S.W + c) * S.D + d] = d <= c ? s : inf;
       }
     }
-    if (d < S.D) C[((size_t)r * S.W + c) * S.D + d] = d <= c ? s : inf;
   }
 }
 
