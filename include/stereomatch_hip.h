@@ -112,6 +112,15 @@ int stm_birchfield_f32(const float *left, const float *right, float *cost,
  *                       ~62N bytes, needs a larger workspace).  Same results bit for bit;
  *                       kept for cross-checking and for callers short of memory. */
 #define STM_SGM_SINGLE_PASSES 2
+/* Corrected-algorithm options (extensions; the default is the reference's behaviour):
+ *   STM_SGM_FULL_MIN    the per-step minimum of the previous costs runs over all D
+ *                       disparities (the reference leaves d = D-1 out).
+ *   STM_SGM_TRUE_PATHS  every inverse diagonal pass starts at the true end of its forward
+ *                       path, so every pixel receives each of the eight directions exactly
+ *                       once (the reference's stored end points make some inverse passes
+ *                       re-walk a corner diagonal and skip others). */
+#define STM_SGM_FULL_MIN 8
+#define STM_SGM_TRUE_PATHS 16
 size_t stm_sgm_workspace_bytes(int H, int W, int D, int batch, int flags);
 int stm_sgm_f32(const float *cost, const float *left, float *out, int H, int W,
                 int D, float penalty1, float penalty2, int flags,

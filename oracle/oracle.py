@@ -47,6 +47,7 @@ def lib():
         L.orc_ssd_entry_f32.restype = c_float
         L.orc_birchfield_f32.argtypes = [_f32p, _f32p, _f32p, c_int, c_int, c_int]
         L.orc_sgm_f32.argtypes = [_f32p, _f32p, _f32p, c_int, c_int, c_int, c_float, c_float]
+        L.orc_sgm_ex_f32.argtypes = [_f32p, _f32p, _f32p, c_int, c_int, c_int, c_float, c_float, c_int]
         L.orc_sgm_num_paths.argtypes = [c_int, c_int]
         L.orc_sgm_num_paths.restype = ctypes.c_size_t
         L.orc_sgm_paths.argtypes = [c_int, c_int, _i16p]
@@ -99,13 +100,16 @@ def birchfield(left, right, max_disparity, out=None):
     return out
 
 
-def sgm(cost_volume, left, penalty1=0.1, penalty2=0.2):
+def sgm(cost_volume, left, penalty1=0.1, penalty2=0.2, full_min=False, true_paths=False):
+    """``full_min`` / ``true_paths`` select the corrected-algorithm variants (extensions of
+    the HIP library); the defaults are the reference's behaviour."""
     cost_volume, cp = _f32(cost_volume)
     left, ip = _f32(left)
     H, W, D = cost_volume.shape
     out = np.zeros((H, W, D), dtype=np.float32)
-    _check(lib().orc_sgm_f32(cp, ip, out.ctypes.data_as(_f32p), H, W, D,
-                             penalty1, penalty2), "sgm")
+    flags = (1 if full_min else 0) | (2 if true_paths else 0)
+    _check(lib().orc_sgm_ex_f32(cp, ip, out.ctypes.data_as(_f32p), H, W, D,
+                                penalty1, penalty2, flags), "sgm")
     return out
 
 

@@ -252,6 +252,7 @@ typedef struct {
   float p1, p2;
   float *prev; /* D + 2 floats, prev[0] and prev[D+1] are +inf borders */
   float *cur;
+  int full_min; /* 0: reference (minimum over d in [0, D-2]); 1: corrected, all of [0, D-1] */
 } orc_sgm_ctx;
 
 static void orc_sgm_run(orc_sgm_ctx *c, int sx, int sy, int dx, int dy,
@@ -271,9 +272,10 @@ static void orc_sgm_run(orc_sgm_ctx *c, int sx, int sy, int dx, int dy,
   for (int i = 1; i < size; ++i) {
     /* min over d in [0, D-2] (Q5); std::min_element keeps the first. */
     float m;
-    if (D >= 2) {
+    if (D >= 2 || c->full_min) {
+      const int dlim = c->full_min ? D : D - 1;
       m = c->prev[1];
-      for (int d = 1; d < D - 1; ++d)
+      for (int d = 1; d < dlim; ++d)
         if (c->prev[d + 1] < m) m = c->prev[d + 1];
     } else {
       m = c->prev[1]; /* empty range: iterator == end() -> element D-1 */
@@ -309,8 +311,14 @@ static void orc_sgm_run(orc_sgm_ctx *c, int sx, int sy, int dx, int dy,
 /* S must be pre-zeroed by the caller to reproduce Semiglobal.__call__
  * (stereomatch/aggregation.py:51 -> zeros_tensor_like); the routine
  * accumulates into it exactly like AggregationOps::RunSemiglobal. */
-int orc_sgm_f32(const float *C, const float *I, float *S, int H, int W, int D,
-                float p1, float p2) {
+/* flags: ORC_SGM_FULL_MIN (1) and ORC_SGM_TRUE_PATHS (2) select the corrected-algorithm
+ * variants the HIP library offers as extensions (STM_SGM_FULL_MIN / STM_SGM_TRUE_PATHS):
+ * the minimum over all D disparities, and inverse passes that start at the true end of
+ * their forward path.  flags = 0 is the reference. */
+#define ORC_SGM_FULL_MIN 1
+#define ORC_SGM_TRUE_PATHS 2
+int orc_sgm_ex_f32(const float *C, const float *I, float *S, int H, int W, int D,
+                   float p1, float p2, int flags) {
   if (!C || !I || !S || H <= 0 || W <= 0 || D <= 0) return ORC_EINVAL;
   if (W >= 32768 || H >= 32768) return ORC_EINVAL;
   const size_t n = orc_num_paths(W, H);
@@ -325,16 +333,25 @@ int orc_sgm_f32(const float *C, const float *I, float *S, int H, int W, int D,
   }
   orc_generate_paths(W, H, tab);
   for (int d = 0; d < D + 2; ++d) b0[d] = b1[d] = INFINITY;
-  orc_sgm_ctx ctx = {C, I, S, H, W, D, p1, p2, b0, b1};
+  orc_sgm_ctx ctx = {C, I, S, H, W, D, p1, p2, b0, b1, (flags & ORC_SGM_FULL_MIN) ? 1 : 0};
   for (size_t i = 0; i < n; ++i) {
     const orc_path *p = &tab[i];
     orc_sgm_run(&ctx, p->sx, p->sy, p->dx, p->dy, p->size);
-    orc_sgm_run(&ctx, p->ex, p->ey, -p->dx, -p->dy, p->size);
+    if (flags & ORC_SGM_TRUE_PATHS)
+      orc_sgm_run(&ctx, p->sx + (p->size - 1) * p->dx, p->sy + (p->size - 1) * p->dy, -p->dx,
+                  -p->dy, p->size);
+    else
+      orc_sgm_run(&ctx, p->ex, p->ey, -p->dx, -p->dy, p->size);
   }
   free(tab);
   free(b0);
   free(b1);
   return ORC_OK;
+}
+
+int orc_sgm_f32(const float *C, const float *I, float *S, int H, int W, int D,
+                float p1, float p2) {
+  return orc_sgm_ex_f32(C, I, S, H, W, D, p1, p2, 0);
 }
 
 /* ------------------------------------------------------------------------

@@ -73,20 +73,20 @@ struct SgmQuirk {
   int wide_extra;  // W - H  when W > H, else 0
   int tall_extra;  // H-W-1 when H > W+1, else 0
 };
-__host__ __device__ inline SgmQuirk sgm_quirk(int H, int W) {
+__host__ __device__ inline SgmQuirk sgm_quirk(int H, int W, bool true_paths) {
   SgmQuirk q;
-  q.wide_extra = W > H ? W - H : 0;
-  q.tall_extra = H > W + 1 ? H - W - 1 : 0;
+  q.wide_extra = (!true_paths && W > H) ? W - H : 0;
+  q.tall_extra = (!true_paths && H > W + 1) ? H - W - 1 : 0;
   return q;
 }
 
-__host__ __device__ inline int sgm_family_paths(int family, int H, int W) {
+__host__ __device__ inline int sgm_family_paths(int family, int H, int W, bool true_paths) {
   switch (family) {
     case kRight: case kLeft: return H;
     case kDown: return W;
     // One extra wave walks the tall-image corner diagonal (compute + spill only) while
     // the vertical inverses run; its repeated adds land between families kUp and kDownRight.
-    case kUp: return W + (sgm_quirk(H, W).tall_extra > 0 ? 1 : 0);
+    case kUp: return W + (sgm_quirk(H, W, true_paths).tall_extra > 0 ? 1 : 0);
     default: return W + H - 1;
   }
 }
@@ -95,7 +95,9 @@ __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 
 // Start, direction and length of path `w` of a family, following GeneratePaths and
 // SGPixelPath::inverse() (src/semiglobal.hpp:42-45) entry by entry.
-__device__ __forceinline__ Walk sgm_decode(int family, int w, int H, int W) {
+// true_paths: every inverse pass starts at the true end of its forward path (the eight
+// directions as published, STM_SGM_TRUE_PATHS) instead of the reference's stored end.
+__device__ __forceinline__ Walk sgm_decode(int family, int w, int H, int W, bool true_paths) {
   Walk k;
   switch (family) {
     case kRight: k = {0, w, 1, 0, W, 1, 0}; break;
@@ -117,13 +119,15 @@ __device__ __forceinline__ Walk sgm_decode(int family, int w, int H, int W) {
       if (w < W) {
         const int ey = imin(w, H - 1);
         k = {W - 1, ey, -1, -1, ey + 1, 1, 0};
-        if (w >= H) k.add = 0;                      // duplicate of w = H-1 (wide)
+        if (true_paths) k = {W - 1 - w + ey, ey, -1, -1, ey + 1, 1, 0};
+        else if (w >= H) k.add = 0;                 // duplicate of w = H-1 (wide)
         else if (w == H - 1 && W > H) k.spill = 1;  // the re-walked diagonal itself
       } else {
         const int i = w - W;
         const int ex = imin(H - 2 - i, W - 1);
         k = {ex, H - 1, -1, -1, ex + 1, 1, 0};
-        if (W - 1 < H - 2 - i) k.add = 0;           // duplicate of i = H-W-1 (tall)
+        if (true_paths) k = {ex, i + 1 + ex, -1, -1, ex + 1, 1, 0};
+        else if (W - 1 < H - 2 - i) k.add = 0;      // duplicate of i = H-W-1 (tall)
       }
       break;
     case kDownLeft:
@@ -138,7 +142,8 @@ __device__ __forceinline__ Walk sgm_decode(int family, int w, int H, int W) {
       if (w < W) {
         const int len = imin(w + 1, H);
         k = {0, len - 1, 1, -1, len, 1, 0};
-        if (w >= H) k.add = 0;                      // stored end (0, H-1): duplicate of w = H-1
+        if (true_paths) k = {w - len + 1, len - 1, 1, -1, len, 1, 0};
+        else if (w >= H) k.add = 0;                 // stored end (0, H-1): duplicate of w = H-1
         else if (w == H - 1 && W > H) k.spill = 1;
       } else {
         const int i = w - W;
@@ -153,15 +158,17 @@ __device__ __forceinline__ Walk sgm_decode(int family, int w, int H, int W) {
 // One step of the recurrence, pixel i-1 -> pixel i of a path (semiglobal.cpp:129-157).
 template <int VPL>
 __device__ __forceinline__ Row<VPL> sgm_step(const Row<VPL> &prev, float prev_i, const Row<VPL> &c,
-                                             float inten, float p1, float p2, int D, int d0) {
+                                             float inten, float p1, float p2, int D, int d0,
+                                             int dlim) {
   const float inf = __builtin_inff();
-  // m over d in [0, D-2]: the element d = D-1 is left out (Q5).
+  // m over d in [0, dlim): dlim = D-1 reproduces the reference, whose minimum leaves the
+  // element d = D-1 out (Q5); dlim = D is the corrected full-range minimum.
   float lm = inf;
 #pragma unroll
   for (int j = 0; j < VPL; ++j)
-    if (d0 + j < D - 1) lm = fminf(lm, prev.v[j]);
+    if (d0 + j < dlim) lm = fminf(lm, prev.v[j]);
   float m = wave_min_f32(lm);
-  if (D == 1) m = read_lane(prev.v[0], 0);  // empty range: *end() is element D-1
+  if (dlim == 0) m = read_lane(prev.v[0], 0);  // D = 1: empty range, *end() is element D-1
   const float q = p2 / fabsf(inten - prev_i);
   const float p2a = p1 < q ? q : p1;  // std::max(p1, q)
   const float far = m + p2a;
@@ -190,7 +197,7 @@ struct Walker {
   const float *__restrict__ image;
   float *__restrict__ out;
   float *__restrict__ spill;  // workspace rows of this image, or nullptr
-  int D, d0;
+  int D, d0, dlim;
   float p1, p2;
   Row<VPL> prev;
   float prev_i;
@@ -202,7 +209,7 @@ struct Walker {
   }
 
   __device__ __forceinline__ Row<VPL> advance(const Row<VPL> &c, float inten) const {
-    return sgm_step<VPL>(prev, prev_i, c, inten, p1, p2, D, d0);
+    return sgm_step<VPL>(prev, prev_i, c, inten, p1, p2, D, d0, dlim);
   }
 
   __device__ __forceinline__ void emit(long q, int i, const Row<VPL> &s, const Row<VPL> &cur,
@@ -292,6 +299,8 @@ struct SgmShape {
   int paths;     // waves per image in this family (sgm_family_paths)
   int batch;
   int ws_rows;   // workspace rows per image (min(H, W)), 0 when there is no workspace
+  int dlim;        // disparities the per-step minimum runs over (D-1: reference, D: corrected)
+  int true_paths;  // 1: inverse passes start at the true path ends
 };
 
 template <int VPL, bool VEC, bool FIRST>
@@ -313,11 +322,12 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pass_kernel(const float *__rest
   wk.out = out_all + (size_t)b * npix * P.D;
   wk.spill = ws_all ? ws_all + (size_t)b * P.ws_rows * P.D : nullptr;
   wk.D = P.D;
+  wk.dlim = P.dlim;
   wk.d0 = lane * VPL;
   wk.p1 = P.p1;
   wk.p2 = P.p2;
 
-  Walk k = sgm_decode(P.family, w, P.H, P.W);
+  Walk k = sgm_decode(P.family, w, P.H, P.W, P.true_paths != 0);
   if (!wk.spill) k.spill = 0;
   if ((k.add | k.spill) && k.len > 0) wk.run(k, P.W);
 }
@@ -378,6 +388,8 @@ struct PairShape {
   int maxseg[4];          // checkpoint slots per path = ceil(maxlen / K) - 1
   long long ckpt_off[4];  // float offset of each pair's checkpoint block in the workspace
   int tall_extra;         // > 0: one extra wave walks the tall corner diagonal (spill only)
+  int dlim;               // see SgmShape
+  int true_paths;
 };
 
 __host__ __device__ inline int sgm_pair_fwd(int pair) { return pair * 2; }      // kRight, kDown, kDownRight, kDownLeft
@@ -411,10 +423,10 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_ckpt_kernel(const float *__rest
   float *ckpt = nullptr;
   float *spill = nullptr;
   if (pair < 4) {
-    k = sgm_decode(sgm_pair_fwd(pair), wave, P.H, P.W);
+    k = sgm_decode(sgm_pair_fwd(pair), wave, P.H, P.W, P.true_paths != 0);
     ckpt = ws_all + P.ckpt_off[pair] + ((size_t)b * P.paths[pair] + wave) * (size_t)P.maxseg[pair] * D;
   } else {
-    k = sgm_decode(kUp, P.W, P.H, P.W);  // the tall corner diagonal, spill only
+    k = sgm_decode(kUp, P.W, P.H, P.W, false);  // the tall corner diagonal, spill only
     spill = ws_all + (size_t)b * P.ws_rows * D;
   }
   if (k.len <= 0) return;
@@ -446,7 +458,7 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_ckpt_kernel(const float *__rest
           ibuf[u] = image[q];
         }
         if (i > 0) {
-          const Row<VPL> cur = sgm_step<VPL>(prev, prev_i, c, inten, P.p1, P.p2, D, d0);
+          const Row<VPL> cur = sgm_step<VPL>(prev, prev_i, c, inten, P.p1, P.p2, D, d0, P.dlim);
           prev = cur;
           prev_i = inten;
           if (spill) store_row<VPL, VEC>(spill, (size_t)i, D, d0, cur);
@@ -484,8 +496,8 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
   const int D = P.D, d0 = lane * VPL;
   const float p1 = P.p1, p2 = P.p2;
 
-  const Walk F = sgm_decode(sgm_pair_fwd(P.pair), w, P.H, P.W);
-  const Walk I = sgm_decode(sgm_pair_inv(P.pair), w, P.H, P.W);
+  const Walk F = sgm_decode(sgm_pair_fwd(P.pair), w, P.H, P.W, P.true_paths != 0);
+  const Walk I = sgm_decode(sgm_pair_inv(P.pair), w, P.H, P.W, P.true_paths != 0);
   if (F.len <= 0) return;
   const bool add_inv = I.add != 0;  // 0: the reference's inverse pass re-walks another diagonal
   float *spill = (I.spill && P.ws_rows > 0) ? ws_all + (size_t)b * P.ws_rows * D : nullptr;
@@ -534,7 +546,7 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
         if (s == 0 && j == 0) {
           fseg[0] = cseg[0];
         } else {
-          fseg[j] = sgm_step<VPL>(fprev, fprev_i, cseg[j], iseg[j], p1, p2, D, d0);
+          fseg[j] = sgm_step<VPL>(fprev, fprev_i, cseg[j], iseg[j], p1, p2, D, d0, P.dlim);
           fprev = fseg[j];
           fprev_i = iseg[j];
         }
@@ -552,7 +564,7 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
           if (s == nseg - 1 && j == n - 1) {
             li = cseg[j];  // first pixel of the inverse pass: L = C
           } else {
-            li = sgm_step<VPL>(inv_prev, inv_prev_i, cseg[j], iseg[j], p1, p2, D, d0);
+            li = sgm_step<VPL>(inv_prev, inv_prev_i, cseg[j], iseg[j], p1, p2, D, d0, P.dlim);
           }
           inv_prev = li;
           inv_prev_i = iseg[j];
@@ -670,9 +682,9 @@ static int sgm_vpl(int D) {
   return VPL;
 }
 
-static SgmPlan sgm_plan(int H, int W, int D, int batch, bool paired) {
+static SgmPlan sgm_plan(int H, int W, int D, int batch, bool paired, bool true_paths) {
   SgmPlan plan;
-  const stm::SgmQuirk q = stm::sgm_quirk(H, W);
+  const stm::SgmQuirk q = stm::sgm_quirk(H, W, true_paths);
   const bool quirk = q.wide_extra > 0 || q.tall_extra > 0;
   plan.spill_floats = quirk ? (size_t)batch * (size_t)(H < W ? H : W) * (size_t)D : 0;
   stm::PairShape &P = plan.P;
@@ -695,7 +707,7 @@ static SgmPlan sgm_plan(int H, int W, int D, int batch, bool paired) {
 
 extern "C" size_t stm_sgm_workspace_bytes(int H, int W, int D, int batch, int flags) {
   if (H <= 0 || W <= 0 || D <= 0 || batch <= 0 || D > STM_MAX_DISPARITY) return 0;
-  return sgm_plan(H, W, D, batch, !(flags & STM_SGM_SINGLE_PASSES)).total_floats * sizeof(float);
+  return sgm_plan(H, W, D, batch, !(flags & STM_SGM_SINGLE_PASSES), (flags & STM_SGM_TRUE_PATHS) != 0).total_floats * sizeof(float);
 }
 
 namespace stm {
@@ -754,7 +766,9 @@ static int sgm_run(const float *cost, const float *left, float *out, int32_t *di
   const bool paired = !(flags & STM_SGM_SINGLE_PASSES);
   STM_REQUIRE(final_mode == 0 || (paired && disp), STM_EINVAL,
               "stm_sgm_wta_f32: needs a disparity pointer and the paired form");
-  SgmPlan plan = sgm_plan(H, W, D, batch, paired);
+  const bool true_paths = (flags & STM_SGM_TRUE_PATHS) != 0;
+  const int dlim = (flags & STM_SGM_FULL_MIN) ? D : D - 1;
+  SgmPlan plan = sgm_plan(H, W, D, batch, paired, true_paths);
   const size_t need = plan.total_floats * sizeof(float);
   STM_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), STM_EWORKSPACE,
               "stm_sgm_f32: needs a workspace of %zu bytes (stm_sgm_workspace_bytes)", need);
@@ -766,13 +780,14 @@ static int sgm_run(const float *cost, const float *left, float *out, int32_t *di
                    ((reinterpret_cast<uintptr_t>(out) & align) == 0) &&
                    (!ws || (reinterpret_cast<uintptr_t>(ws) & align) == 0);
   hipStream_t s = as_stream(stream);
-  const SgmQuirk quirk = sgm_quirk(H, W);
+  const SgmQuirk quirk = sgm_quirk(H, W, true_paths);
   const bool accumulate = (flags & STM_SGM_ACCUMULATE) != 0;
   int rc = STM_OK;
 
   if (paired) {
     PairShape &P = plan.P;
     P.p1 = penalty1; P.p2 = penalty2;
+    P.dlim = dlim; P.true_paths = true_paths ? 1 : 0;
     switch (VPL) {
       case 1: rc = launch_ckpt<1>(cost, left, ws, P, vec, s); break;
       case 2: rc = launch_ckpt<2>(cost, left, ws, P, vec, s); break;
@@ -815,9 +830,10 @@ static int sgm_run(const float *cost, const float *left, float *out, int32_t *di
   SgmShape P;
   P.H = H; P.W = W; P.D = D; P.p1 = penalty1; P.p2 = penalty2; P.batch = batch;
   P.ws_rows = plan.P.ws_rows;
+  P.dlim = dlim; P.true_paths = true_paths ? 1 : 0;
   for (int family = 0; family < 8; ++family) {
     P.family = family;
-    P.paths = sgm_family_paths(family, H, W);
+    P.paths = sgm_family_paths(family, H, W, true_paths);
     const bool first = family == 0 && !accumulate;
     switch (VPL) {
       case 1: rc = launch_family<1>(cost, left, out, ws, P, vec, first, s); break;

@@ -18,6 +18,8 @@ STM_SSD_MODES = {"auto": 0, "ordered": 1, "box": 2}
 STM_SGM_ACCUMULATE = 1
 STM_SGM_SINGLE_PASSES = 2
 STM_SGM_KEEP_SUM = 4
+STM_SGM_FULL_MIN = 8
+STM_SGM_TRUE_PATHS = 16
 STM_DP_MODES = {"reference": 0, "corrected": 1}
 
 # name -> (restype, argtypes); every symbol include/stereomatch_hip.h declares.

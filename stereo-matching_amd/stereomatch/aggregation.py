@@ -21,9 +21,18 @@ class Semiglobal:
     gives the same values without the extra fill and read.
     """
 
-    def __init__(self, penalty1: float = 0.1, penalty2: float = 0.2, single_passes: bool = False):
+    def __init__(self, penalty1: float = 0.1, penalty2: float = 0.2, single_passes: bool = False,
+                 paths: str = "reference", full_min: bool = False):
+        if paths not in ("reference", "hirschmuller"):
+            raise ValueError("Semiglobal paths must be 'reference' or 'hirschmuller'")
         self.penalty1 = penalty1
         self.penalty2 = penalty2
+        # Corrected-algorithm options (extensions; the defaults reproduce the reference):
+        # paths="hirschmuller": every pixel receives each of the eight directions exactly once
+        # (the reference's inverse diagonals skip 17-44 % of the pixels, SURVEY A.3 Q6);
+        # full_min=True: the per-step minimum covers all D disparities (Q5).
+        self.paths = paths
+        self.full_min = full_min
         # False (default): a direction and its inverse share one pass over the sum (less HBM
         # traffic, larger workspace); True: eight separate passes.  Same bits either way.
         self.single_passes = single_passes
@@ -65,6 +74,10 @@ class Semiglobal:
         image = left_image.float().contiguous()
         lib = _native.lib()
         flags = _native.STM_SGM_SINGLE_PASSES if self.single_passes else 0
+        if self.paths == "hirschmuller":
+            flags |= _native.STM_SGM_TRUE_PATHS
+        if self.full_min:
+            flags |= _native.STM_SGM_FULL_MIN
         if fused:
             disparity_img = output_tensor(cost_volume.shape[:-1], torch.int32, device,
                                           reuse=disparity_img)

@@ -418,3 +418,38 @@ def test_degenerate_shapes_full_chain(device, oracle, H, W, D):
     assert_same_bits(fused.cpu().numpy(), oracle.wta(Sh), "fused wta")
     dp = stereomatch.disparity_reduce.DynamicProgramming(mode="corrected")
     assert_same_bits(dp(S).cpu().numpy(), oracle.dp(Sh, mode=1), "dp corrected")
+
+
+# ------------------------------------------- corrected-algorithm options (extensions)
+@pytest.mark.parametrize("H,W,D", [(24, 40, 16), (40, 24, 16), (30, 30, 64), (13, 50, 128), (50, 13, 128),
+                                    (9, 21, 256), (6, 8, 1), (10, 14, 100)])
+@pytest.mark.parametrize("paths,full_min", [("hirschmuller", False), ("reference", True),
+                                             ("hirschmuller", True)])
+@pytest.mark.parametrize("single", [False, True])
+def test_sgm_corrected_modes_match_oracle(device, oracle, H, W, D, paths, full_min, single):
+    import stereomatch
+    rng = np.random.default_rng(H + 2 * W + D)
+    C = _random_volume(rng, H, W, D, "last")     # minima at d = D-1 make full_min matter
+    image = rng.integers(0, 9, size=(H, W)).astype(np.float32)
+    want = oracle.sgm(C, image, 0.1, 0.2, full_min=full_min, true_paths=(paths == "hirschmuller"))
+    if D > 1 and (full_min or (paths == "hirschmuller" and H != W)):
+        assert not np.array_equal(want, oracle.sgm(C, image, 0.1, 0.2))   # the option matters
+    sgm = stereomatch.aggregation.Semiglobal(0.1, 0.2, single_passes=single, paths=paths,
+                                             full_min=full_min)
+    got = sgm(_gpu(C, device), _gpu(image, device))
+    assert_same_bits(got.cpu().numpy(), want, "sgm %s full_min=%s" % (paths, full_min))
+    if not single:
+        _, disp = sgm.aggregate_and_reduce(_gpu(C, device), _gpu(image, device))
+        assert_same_bits(disp.cpu().numpy(), oracle.wta(want), "fused, corrected modes")
+
+
+def test_true_paths_visit_every_pixel_eight_times(device):
+    """With unit costs in a 1-disparity volume every pass adds exactly 1 per visited pixel:
+    the corrected path set gives 8 everywhere, the reference's does not on non-square images."""
+    import stereomatch
+    C = torch.ones(20, 33, 1, device=device)
+    image = torch.zeros(20, 33, device=device)
+    fixed = stereomatch.aggregation.Semiglobal(paths="hirschmuller")(C, image)
+    assert torch.equal(fixed, torch.full_like(fixed, 8.0))
+    ref = stereomatch.aggregation.Semiglobal()(C, image)
+    assert float(ref.min()) == 6.0 and float(ref.max()) == 6.0 + 2 * (33 - 20 + 1)
