@@ -453,3 +453,22 @@ def test_true_paths_visit_every_pixel_eight_times(device):
     assert torch.equal(fixed, torch.full_like(fixed, 8.0))
     ref = stereomatch.aggregation.Semiglobal()(C, image)
     assert float(ref.min()) == 6.0 and float(ref.max()) == 6.0 + 2 * (33 - 20 + 1)
+
+
+def test_cli_image_end_to_end(device, oracle, tmp_path):
+    """stm-image equivalent: 8-bit PNGs in, 16-bit disparity PNG out, same numbers as the
+    oracle chain on the unscaled grey values (upstream cli_image.py:70-83)."""
+    from PIL import Image
+    from stereomatch import cli_image
+    L, R = oracle.synthetic_pair(40, 64, seed=12)
+    Image.fromarray(L.astype(np.uint8)).save(tmp_path / "l.png")
+    Image.fromarray(R.astype(np.uint8)).save(tmp_path / "r.png")
+    out = tmp_path / "d.png"
+    assert cli_image.main([str(tmp_path / "l.png"), str(tmp_path / "r.png"), "32", str(out),
+                           "-am", "sgm", "-c"]) == 0
+    got = np.array(Image.open(out)).astype(np.int32)
+    want = oracle.wta(oracle.sgm(oracle.ssd(L, R, 32), L))
+    assert np.array_equal(got, want)
+    cli_image.main([str(tmp_path / "l.png"), str(tmp_path / "r.png"), "16", str(tmp_path / "d.npy"),
+                    "-cm", "birchfield", "-dm", "dyn"])
+    assert np.load(tmp_path / "d.npy").shape == (40, 64)

@@ -134,3 +134,56 @@ def test_pair_shard_partitions():
     assert [pair_shard(64, r, 8) for r in (0, 7)] == [(0, 8), (56, 64)]     # config 5
     with pytest.raises(ValueError):
         pair_shard(4, 2, 2)
+
+
+def test_create_pipeline_registry_matches_reference_names():
+    """Upstream cli_common.py:9-52 (the texture cost is not offered on CDNA4)."""
+    import stereomatch
+    from stereomatch.cli_common import (AGGREGATION_METHODS, COST_METHODS, DISPARITY_METHODS,
+                                        create_pipeline)
+    assert sorted(COST_METHODS) == ["birchfield", "ssd"]
+    assert sorted(AGGREGATION_METHODS) == ["sgm"] and sorted(DISPARITY_METHODS) == ["dyn", "wta"]
+    pipe = create_pipeline("ssd", "wta", "sgm", max_disparity=64)
+    assert isinstance(pipe.cost, stereomatch.cost.SSD) and pipe.cost.max_disparity == 64
+    assert isinstance(pipe.aggregation, stereomatch.aggregation.Semiglobal)
+    assert isinstance(pipe.disparity_reduce, stereomatch.disparity_reduce.WinnerTakesAll)
+    assert create_pipeline("birchfield", "dyn", None).aggregation is None
+    assert create_pipeline("ssd", "wta").cost.max_disparity == 32      # upstream default
+
+
+def test_middlebury_reader_and_metrics(tmp_path):
+    """Upstream data.py:26-93 (its own test is skipped, tests/test_data.py:9): a synthetic
+    scene tree with PNG pairs, PFM ground truth and calib.txt."""
+    from PIL import Image
+    from stereomatch.data import MiddleburyDataset, disparity_metrics, read_pfm, write_pfm
+    rng = np.random.default_rng(0)
+    truth = {}
+    for name in ("scene10", "scene2", "artroom1"):
+        d = tmp_path / name
+        d.mkdir()
+        left = rng.integers(0, 256, size=(12, 20, 3), dtype=np.uint8)
+        right = rng.integers(0, 256, size=(12, 20, 3), dtype=np.uint8)
+        gt = rng.random((12, 20), dtype=np.float32) * 30
+        gt[0, :3] = np.inf
+        Image.fromarray(left).save(d / "im0.png")
+        Image.fromarray(right).save(d / "im1.png")
+        write_pfm(d / "disp0.pfm", gt)
+        (d / "calib.txt").write_text("cam0=[1 0 0; 0 1 0; 0 0 1]\nwidth=20\nheight=12\nndisp=48\n")
+        truth[name] = (left, right, gt)
+    (tmp_path / "README.txt").write_text("not a scene")
+    ds = MiddleburyDataset(str(tmp_path))
+    assert [ds[i]["stereo_name"] for i in range(len(ds))] == ["artroom1", "scene2", "scene10"]
+    item = ds[1]
+    left, right, gt = truth["scene2"]
+    assert item["max_disparity"] == 48
+    assert np.array_equal(item["left"].numpy(), left) and np.array_equal(item["right"].numpy(), right)
+    assert np.array_equal(item["gt_disparity"].numpy(), gt)          # top-down, inf kept
+    assert len(MiddleburyDataset(str(tmp_path), max_size=2)) == 2
+    assert np.array_equal(read_pfm(tmp_path / "scene2" / "disp0.pfm"), gt)
+    est = np.where(np.isfinite(gt), gt, 0) + 1.5
+    m = disparity_metrics(est, gt)
+    assert m["valid_pixels"] == 12 * 20 - 3
+    assert abs(m["rmse"] - 1.5) < 1e-6 and abs(m["avgerr"] - 1.5) < 1e-6
+    assert m["bad1"] == 100.0 and m["bad2"] == 0.0
+    with pytest.raises(RuntimeError):
+        MiddleburyDataset(str(tmp_path / "nope"))
