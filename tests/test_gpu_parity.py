@@ -472,3 +472,32 @@ def test_cli_image_end_to_end(device, oracle, tmp_path):
     cli_image.main([str(tmp_path / "l.png"), str(tmp_path / "r.png"), "16", str(tmp_path / "d.npy"),
                     "-cm", "birchfield", "-dm", "dyn"])
     assert np.load(tmp_path / "d.npy").shape == (40, 64)
+
+
+def test_integration_stub_presents_the_reference_extension_api(device, oracle):
+    """a module with the reference's three static-method classes
+    (src/_cstereomatch.cpp:10-17) over the C ABI, called with the reference's argument lists
+    and caller-allocated outputs (cost.py:44-46, aggregation.py:51-55, disparity_reduce.py:45,77-88)."""
+    import cstereomatch_hip_stub as ext
+    H, W, D = 24, 40, 16
+    L, R = oracle.synthetic_pair(H, W, seed=0)
+    Lg, Rg = _gpu(L, device), _gpu(R, device)
+    cost = torch.empty(H, W, D, device=device)
+    ext.CostOps.compute_ssd(Lg, Rg, cost, 7)
+    assert_same_bits(cost.cpu().numpy(), oracle.ssd(L, R, D, 7), "stub ssd")
+    bt = torch.zeros(H, W, D, device=device)
+    ext.CostOps.compute_birchfield(Lg, Rg, bt, 4)
+    assert_same_bits(bt.cpu().numpy(), oracle.birchfield(L, R, D), "stub birchfield")
+    agg = torch.zeros_like(cost)                       # zeros_tensor_like, then "+=" semantics
+    ext.AggregationOps.run_semiglobal(cost, Lg, 0.1, 0.2, agg)
+    want = oracle.sgm(oracle.ssd(L, R, D, 7), L)
+    assert_same_bits(agg.cpu().numpy(), want, "stub sgm")
+    disp = torch.empty(H, W, dtype=torch.int32, device=device)
+    ext.DisparityReduceOps.run_winners_take_all(agg, disp)
+    assert_same_bits(disp.cpu().numpy(), oracle.wta(want), "stub wta")
+    path = torch.empty(H, W, D, dtype=torch.int8, device=device)      # torch.empty, as upstream
+    final = torch.empty(H, D, device=device)
+    ext.DisparityReduceOps.run_dynamic_programming(agg, path, final, disp)
+    assert_same_bits(disp.cpu().numpy(), oracle.dp(want), "stub dp")
+    with pytest.raises(RuntimeError):
+        ext.DisparityReduceOps.run_dynamic_programming(torch.zeros(4, 2, 8, device=device), path, final, disp)
