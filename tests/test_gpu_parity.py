@@ -501,3 +501,44 @@ def test_integration_stub_presents_the_reference_extension_api(device, oracle):
     assert_same_bits(disp.cpu().numpy(), oracle.dp(want), "stub dp")
     with pytest.raises(RuntimeError):
         ext.DisparityReduceOps.run_dynamic_programming(torch.zeros(4, 2, 8, device=device), path, final, disp)
+
+
+# ------------------------------------------------- widest disparity ranges, batched quirks
+@pytest.mark.parametrize("H,W,D", [(6, 10, 1024), (5, 9, 768), (12, 7, 512), (1030, 1040, 1024)][:3])
+def test_largest_disparity_ranges(device, oracle, H, W, D):
+    """D = 512..1024 exercise the 8- and 16-values-per-lane kernels and the 32/64-step DP tiles."""
+    import stereomatch
+    rng = np.random.default_rng(D + H)
+    C = _random_volume(rng, H, W, D, "float")
+    image = rng.integers(0, 7, size=(H, W)).astype(np.float32)
+    Cg, Ig = _gpu(C, device), _gpu(image, device)
+    want = oracle.sgm(C, image)
+    for single in (False, True):
+        S = stereomatch.aggregation.Semiglobal(single_passes=single)(Cg, Ig)
+        assert_same_bits(S.cpu().numpy(), want, "sgm D=%d single=%s" % (D, single))
+    wta = stereomatch.disparity_reduce.WinnerTakesAll(require_power_of_two=False)
+    assert_same_bits(wta(S).cpu().numpy(), oracle.wta(want), "wta")
+    dp = stereomatch.disparity_reduce.DynamicProgramming(mode="corrected")
+    assert_same_bits(dp(S).cpu().numpy(), oracle.dp(want, mode=1), "dp")
+    L, R = oracle.synthetic_pair(H, W, seed=D)
+    got = stereomatch.cost.SSD(D)(_gpu(L, device), _gpu(R, device))
+    assert_same_bits(got.cpu().numpy(), oracle.ssd(L, R, D, 7), "ssd")
+    bt = stereomatch.cost.Birchfield(D)(_gpu(L, device), _gpu(R, device))
+    assert_same_bits(bt.cpu().numpy(), oracle.birchfield(L, R, D), "birchfield")
+
+
+@pytest.mark.parametrize("H,W", [(14, 31), (31, 14)])
+def test_batched_sgm_with_rewalked_diagonals(device, oracle, H, W):
+    """Wide and tall images in a batch: every pair has its own spill rows and checkpoints."""
+    import stereomatch
+    D, B = 64, 3
+    rng = np.random.default_rng(H)
+    C = np.stack([_random_volume(rng, H, W, D, "float") for _ in range(B)])
+    image = rng.integers(0, 5, size=(B, H, W)).astype(np.float32)
+    for single in (False, True):
+        S = stereomatch.aggregation.Semiglobal(single_passes=single)(_gpu(C, device), _gpu(image, device))
+        for b in range(B):
+            assert_same_bits(S[b].cpu().numpy(), oracle.sgm(C[b], image[b]), "batched sgm %d" % b)
+    _, disp = stereomatch.aggregation.Semiglobal().aggregate_and_reduce(_gpu(C, device), _gpu(image, device))
+    for b in range(B):
+        assert_same_bits(disp[b].cpu().numpy(), oracle.wta(oracle.sgm(C[b], image[b])), "batched fused")
