@@ -164,12 +164,14 @@ def roofline(job, sgm_ms, traffic=None):
             "algorithmic_bytes": algorithmic, "ms": round(sgm_ms, 4)}
 
 
-def load_traffic(name):
-    """HBM bytes per aggregation from the committed PMC summary, if there is one."""
+def load_traffic(name, batch):
+    """HBM bytes the aggregation stage moves per step: the per-pair figure of the committed
+    PMC summary (profiles/traffic.json) times the pairs per step; None without a summary."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(name)
+            per_pair = json.load(f).get(name + "_per_pair")
+        return None if per_pair is None else int(per_pair) * batch
     except (OSError, ValueError):
         return None
 
@@ -283,7 +285,7 @@ def main():
                    "penalties": [0.1, 0.2], "sharding": "pairs over ranks, all_gather of disparity maps"},
         "stage_ms": {"ssd": round(stage_ms[0], 4), "sgm_wta_fused": round(stage_ms[1], 4),
                      "sgm_alone_unfused": round(job.unfused_sgm_ms(), 4)},
-        "roofline": roofline(job, stage_ms[1], load_traffic(name)),
+        "roofline": roofline(job, stage_ms[1], load_traffic(name, batch)),
     }
     del job
     torch.cuda.empty_cache()
@@ -300,7 +302,7 @@ def main():
             "ms_per_step": round(e2 / args.also_steps * 1e3, 3),
             "stage_ms": {"ssd": round(s2[0], 4), "sgm_wta_fused": round(s2[1], 4),
                          "sgm_alone_unfused": round(job2.unfused_sgm_ms(), 4)},
-            "roofline": roofline(job2, s2[1], load_traffic(args.also)),
+            "roofline": roofline(job2, s2[1], load_traffic(args.also, b2)),
             "pixels_at_true_disparity": round(d7, 4),
         }
         del job2

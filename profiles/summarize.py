@@ -31,7 +31,10 @@ def load(path):
 
 def main():
     tag, trace_dir, fetch_dir, write_dir = sys.argv[1:5]
-    prefix = sys.argv[5] if len(sys.argv) > 5 else "r01"
+    prefix = "r01"
+    # pairs per step of the two workloads in the profiled bench runs (per-pair figures are stored)
+    batches = {"teddy": int(sys.argv[5]) if len(sys.argv) > 5 else 64,
+               "1080p": int(sys.argv[6]) if len(sys.argv) > 6 else 4}
     trace = load(os.path.join(trace_dir, prefix + "_kernel_trace.csv"))
     agg = collections.defaultdict(list)
     for r in trace:
@@ -86,14 +89,16 @@ def main():
     traffic = {}
     for wl, vpl in (("teddy", 2), ("1080p", 4)):
         o = per_step(vpl)
-        traffic[wl] = round(o[("FETCH_SIZE", True)] + o[("WRITE_SIZE", True)])
-        traffic[wl + "_detail"] = {
-            "fused_fetch_bytes_corrected": round(o[("FETCH_SIZE", True)]),
-            "fused_write_bytes": round(o[("WRITE_SIZE", True)]),
-            "unfused_fetch_bytes_corrected": round(o[("FETCH_SIZE", False)]),
-            "unfused_write_bytes": round(o[("WRITE_SIZE", False)])}
-    traffic["_note"] = ("HBM bytes per fused aggregation+WTA of one bench step (Teddy: 16 pairs, "
-                        "1080p: 4 pairs), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; "
+        nb = batches[wl]
+        traffic[wl + "_per_pair"] = round((o[("FETCH_SIZE", True)] + o[("WRITE_SIZE", True)]) / nb)
+        traffic[wl + "_detail_per_pair"] = {
+            "pairs_per_step_when_profiled": nb,
+            "fused_fetch_bytes_corrected": round(o[("FETCH_SIZE", True)] / nb),
+            "fused_write_bytes": round(o[("WRITE_SIZE", True)] / nb),
+            "unfused_fetch_bytes_corrected": round(o[("FETCH_SIZE", False)] / nb),
+            "unfused_write_bytes": round(o[("WRITE_SIZE", False)] / nb)}
+    traffic["_note"] = ("HBM bytes per stereo pair of the fused aggregation+WTA stage (bench.py "
+                        "multiplies by its pairs per step), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; "
                         "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128 B request); "
                         "tag " + tag)
     with open(os.path.join(HERE, "traffic.json"), "w") as f:
