@@ -214,19 +214,36 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
     init[rq][d] = x;
   }
 
-  // Cooperative fetch of the cost pieces block `blk` will consume: instruction u, lane i
-  // serves piece pi = u*PPI + i/LP (the piece lane pi owns), 16-byte part i%LP.
-  auto fetch = [&](int blk, float4 (&regs)[LP]) {
+  // Cooperative fetch of the cost pieces a block will consume: instruction u, lane i serves
+  // piece pi = u*PPI + i/LP (the piece lane pi owns), 16-byte part i%LP.  The position of
+  // every served piece advances by one chunk per block (O disparities down its column, then
+  // on to the column 16 to the right), so it is kept incrementally; pieces without work
+  // read as +inf, which turns into +inf outputs without a select in the dependent chain.
+  int fq[LP], fcol[LP], fd0[LP];
+  size_t fat[LP];
+  bool frow[LP];
+#pragma unroll
+  for (int u = 0; u < LP; ++u) {
+    const int pi = u * PPI + lane / LP, part = lane % LP;
+    const int prow = blockIdx.x * 4 + (pi >> 4), pv = pi & 15;
+    frow[u] = prow < H;
+    fq[u] = -pv;            // blocks until the owner's first column starts
+    fcol[u] = pv;
+    fd0[u] = 0;
+    fat[u] = ((size_t)(frow[u] ? prow : 0) * W + pv) * D + 4 * part;
+  }
+  auto fetch = [&](float4 (&regs)[LP]) {  // fetches the next block's pieces, then advances
 #pragma unroll
     for (int u = 0; u < LP; ++u) {
-      const int pi = u * PPI + lane / LP, part = lane % LP;
-      const int prow = blockIdx.x * 4 + (pi >> 4), pv = pi & 15;
-      const int q = blk - pv;
-      const int pcol = pv + 16 * (q >> 4), pd0 = O * (q & 15);
-      const bool ok = q >= 0 && pcol < W && pd0 < D && prow < H;
-      const size_t at = ok ? ((size_t)prow * W + pcol) * D + pd0 + 4 * part : 0;
-      const float4 x = *reinterpret_cast<const float4 *>(vol + at);
-      regs[u] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool ok = fq[u] >= 0 && fcol[u] < W && fd0[u] < D && frow[u];
+      const float4 x = *reinterpret_cast<const float4 *>(vol + (ok ? fat[u] : 0));
+      regs[u] = ok ? x : make_float4(inf, inf, inf, inf);
+      if (fq[u] >= 0) {
+        fd0[u] += O;
+        fat[u] += O;
+        if (fd0[u] == P) { fd0[u] = 0; fcol[u] += 16; fat[u] += (size_t)16 * D - P; }
+      }
+      ++fq[u];
     }
   };
   auto park = [&](int buf, const float4 (&regs)[LP]) {
@@ -239,7 +256,7 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
   };
 
   float4 regs[LP];
-  fetch(0, regs);
+  fetch(regs);
   park(0, regs);
   float hist[O];
 #pragma unroll
@@ -248,7 +265,7 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
   const int nblocks = W + 15;
   for (int blk = 0; blk < nblocks; ++blk) {
     const int cur = blk & 1;
-    fetch(blk + 1, regs);  // in flight while this block computes
+    fetch(regs);  // the next block's pieces: in flight while this block computes
     const int q = blk - v;
     const int col = v + 16 * (q >> 4);
     const int d0 = O * (q & 15);
@@ -258,10 +275,7 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
     // their outputs +inf without a select in the chain.
     float cst[O], outs[O];
 #pragma unroll
-    for (int j = 0; j < O; ++j) {
-      const float x = tile[cur][lane * LD + j];
-      cst[j] = live ? x : inf;
-    }
+    for (int j = 0; j < O; ++j) cst[j] = tile[cur][lane * LD + j];
     unsigned pk[LP];
 #pragma unroll
     for (int u = 0; u < LP; ++u) pk[u] = 0;
@@ -277,7 +291,7 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
         const float c1 = d > 0 ? prev : inf;
         const float m23 = c2 < c3 ? c2 : c3;
         const float m = c1 < m23 ? c1 : m23;
-        const float out = col0 ? init[rq][d < P ? d : 0] : cst[j] + m;
+        const float out = col0 ? init[rq][d < P ? d : 0] : cst[j] + m;  // +inf when not live
         const int dir = col0 ? 0 : (c1 < m23 ? -1 : (c2 < c3 ? 0 : 1));
         prev = out;
         outs[j] = out;
@@ -292,9 +306,12 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
 #pragma unroll
       for (int j = 0; j < O; ++j) {
         const float c2 = hist[j];
-        const float c3 = d0 + j < D - 1 ? hist[(j + 1) % O] : inf;
+        // Only the last element of a chunk can be d = D-1 (chunks are O-aligned, D % O == 0).
+        const float c3 = (j < O - 1 || d0 + O < D) ? hist[(j + 1) % O] : inf;
         const float m23 = c2 < c3 ? c2 : c3;
-        const float out = cst[j] + fminf(c1, m23);
+        float t;  // v_min_f32 without the canonicalising v_max hipcc puts in front of fminf
+        asm("v_min_f32 %0, %1, %2" : "=v"(t) : "v"(c1), "v"(m23));
+        const float out = cst[j] + t;
         const int dir = c1 < m23 ? -1 : (c2 < c3 ? 0 : 1);
         outs[j] = out;
         pk[j / 4] |= (unsigned)(dir & 0xff) << (8 * (j % 4));
