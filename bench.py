@@ -97,6 +97,8 @@ class Job:
                                          self.sgm)
         self.disp = None
         self.gathered = None
+        self.stage = None
+        self.pending = None
         self.n_elems = H * W * D
 
     def step(self, events=None, world=1):
@@ -108,12 +110,27 @@ class Job:
         if ev is not None:
             ev[2].record()
         if world > 1:
+            # The only collective of the job: every rank ends up with all disparity maps.
             import torch.distributed as dist
-            if self.gathered is None:
-                self.gathered = torch.empty((world,) + tuple(self.disp.shape), dtype=torch.int32,
-                                            device=self.device)
-            dist.all_gather_into_tensor(self.gathered, self.disp)
+            if dist.get_backend() == "nccl":
+                # RCCL all-gather on its own stream, overlapped with the next step's kernels:
+                # the maps are staged out of the pipeline's (reused) output buffer first.
+                if self.gathered is None:
+                    self.stage = torch.empty_like(self.disp)
+                    self.gathered = torch.empty((world,) + tuple(self.disp.shape),
+                                                dtype=torch.int32, device=self.device)
+                self.finish_gather()
+                self.stage.copy_(self.disp)
+                self.pending = dist.all_gather_into_tensor(self.gathered, self.stage, async_op=True)
+            else:  # rehearsal backends
+                from stereomatch.distributed import gather_disparities
+                self.gathered = gather_disparities(self.disp, n_pairs=self.batch * world)
         return self.disp
+
+    def finish_gather(self):
+        if getattr(self, "pending", None) is not None:
+            self.pending.wait()
+            self.pending = None
 
     def unfused_sgm_ms(self, reps=3):
         """stm_sgm_f32 alone (aggregated volume written out) on the resident cost volume."""
@@ -134,6 +151,7 @@ def timed_run(job, steps, warmup, world):
     import torch.distributed as dist
     for _ in range(warmup):
         job.step(world=world)
+    job.finish_gather()
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
     if world > 1:
         dist.barrier()
@@ -141,12 +159,14 @@ def timed_run(job, steps, warmup, world):
     t0 = time.perf_counter()
     for k in range(steps):
         job.step(events[k], world=world)
+    job.finish_gather()      # the last step's gather is part of the timed job
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=job.device)
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device=job.device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stage_ms = [float(np.mean([e[i].elapsed_time(e[i + 1]) for e in events])) for i in range(2)]
@@ -246,17 +266,25 @@ def main():
     ap.add_argument("--also-batch", type=int, default=0, help="pairs per step of the second workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config3", action="store_true", help="skip the Birchfield+SGM+DP extra line")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--shared-device", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (with --backend gloo) on a 1-GPU box")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    if args.shared_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=args.backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
 
     from stereomatch import _native

@@ -52,6 +52,12 @@ def gather_disparities(local: torch.Tensor, n_pairs: Optional[int] = None,
         pad = torch.zeros((width - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,
                           device=local.device)
         padded = torch.cat([local, pad], dim=0)
+    if dist.get_backend(group) != "nccl" and padded.is_cuda:
+        # Rehearsal backends (gloo) gather through host memory.
+        host = padded.cpu()
+        pieces = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(pieces, host, group=group)
+        return torch.cat([p[:c] for p, c in zip(pieces, counts)], dim=0).to(padded.device)
     pieces = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(pieces, padded, group=group)
     return torch.cat([p[:c] for p, c in zip(pieces, counts)], dim=0)
