@@ -40,6 +40,7 @@ for _p in (ROOT, os.path.join(ROOT, "stereo-matching_amd")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+FORCE_GATHER = False  # --rehearse-nccl: run the gather code path in a 1-rank RCCL group
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 WORKLOADS = {
@@ -101,7 +102,7 @@ class Job:
         self.pending = None
         self.n_elems = H * W * D
 
-    def step(self, events=None, world=1):
+    def step(self, events=None, world=1, gather=None):
         ev = events
         if ev is not None:
             ev[0].record()
@@ -109,7 +110,7 @@ class Job:
         self.disp = self.pipe.estimate(self.left, self.right)
         if ev is not None:
             ev[2].record()
-        if world > 1:
+        if world > 1 or (gather if gather is not None else FORCE_GATHER):
             # The only collective of the job: every rank ends up with all disparity maps.
             import torch.distributed as dist
             if dist.get_backend() == "nccl":
@@ -267,6 +268,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config3", action="store_true", help="skip the Birchfield+SGM+DP extra line")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--rehearse-nccl", action="store_true",
+                    help="rehearsal only: 1-rank RCCL group, gather code path exercised")
     ap.add_argument("--shared-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (with --backend gloo) on a 1-GPU box")
     args = ap.parse_args()
@@ -279,6 +282,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if args.rehearse_nccl and world == 1:
+        import torch.distributed as dist
+        global FORCE_GATHER
+        FORCE_GATHER = True
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)
     if world > 1:
         import torch.distributed as dist
         if args.backend == "nccl":
