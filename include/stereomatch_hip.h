@@ -93,6 +93,13 @@ int stm_ssd_f32(const float *left, const float *right, float *cost, int H,
  */
 int stm_birchfield_f32(const float *left, const float *right, float *cost,
                        int H, int W, int D, int batch, void *stream);
+/* Same with options (extension).  STM_BT_PADDED: the sample indexing of the reference's
+ * CUDA functor (src/birchfield_cost.cu:92-139: centre sample p, neighbours p-1 / p+1, zero
+ * outside the row) instead of the CPU functor's shifted flat indexing. */
+#define STM_BT_PADDED 1
+int stm_birchfield_ex_f32(const float *left, const float *right, float *cost,
+                          int H, int W, int D, int flags, int batch,
+                          void *stream);
 
 /* ---- Semiglobal aggregation (src/semiglobal.cpp:18-160,167-197) ----------------
  * out = sum over the reference's path passes of L_r, accumulated in the

@@ -46,6 +46,7 @@ def lib():
         L.orc_ssd_entry_f32.argtypes = [_f32p, _f32p, c_int, c_int, c_int, c_int, c_int, c_int]
         L.orc_ssd_entry_f32.restype = c_float
         L.orc_birchfield_f32.argtypes = [_f32p, _f32p, _f32p, c_int, c_int, c_int]
+        L.orc_birchfield_ex_f32.argtypes = [_f32p, _f32p, _f32p, c_int, c_int, c_int, c_int]
         L.orc_sgm_f32.argtypes = [_f32p, _f32p, _f32p, c_int, c_int, c_int, c_float, c_float]
         L.orc_sgm_ex_f32.argtypes = [_f32p, _f32p, _f32p, c_int, c_int, c_int, c_float, c_float, c_int]
         L.orc_sgm_num_paths.argtypes = [c_int, c_int]
@@ -87,16 +88,17 @@ def ssd_entries(left, right, kernel_size, rows, cols, disps):
                      for r, c, d in zip(rows, cols, disps)], dtype=np.float32)
 
 
-def birchfield(left, right, max_disparity, out=None):
-    """Entries d > x are left untouched (zero when ``out`` is None)."""
+def birchfield(left, right, max_disparity, out=None, padded=False):
+    """Entries d > x are left untouched (zero when ``out`` is None).  ``padded`` selects the
+    CUDA functor's sample indexing (an opt-in extension of the HIP library)."""
     left, lp = _f32(left)
     right, rp = _f32(right)
     H, W = left.shape
     if out is None:
         out = np.zeros((H, W, max_disparity), dtype=np.float32)
     assert out.dtype == np.float32 and out.flags.c_contiguous
-    _check(lib().orc_birchfield_f32(lp, rp, out.ctypes.data_as(_f32p), H, W,
-                                    max_disparity), "birchfield")
+    _check(lib().orc_birchfield_ex_f32(lp, rp, out.ctypes.data_as(_f32p), H, W,
+                                       max_disparity, 1 if padded else 0), "birchfield")
     return out
 
 

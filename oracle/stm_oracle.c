@@ -130,8 +130,29 @@ static inline float bt_term(const float *L, const float *R, size_t n,
   return b < a ? b : a; /* min(a, b) */
 }
 
-int orc_birchfield_f32(const float *L, const float *R, float *C, int H, int W,
-                       int D) {
+/* padded = 1: the sample indexing of the reference's CUDA functor
+ * (src/birchfield_cost.cu:92-139: the scanline copied to shared memory at offset 1 with zero
+ * borders, so tap p reads row[p] with neighbours row[p-1], row[p+1], zero outside the row);
+ * an opt-in extension of the HIP library (STM_BT_PADDED).  padded = 0: the CPU functor. */
+static inline float row_at(const float *row, int W, int idx) {
+  return (idx >= 0 && idx < W) ? row[idx] : 0.0f;
+}
+
+static inline float bt_term_padded(const float *Lr, const float *Rr, int W, int p, int q) {
+  const float l = row_at(Lr, W, p), r = row_at(Rr, W, q);
+  const float la = 0.5f * (l + row_at(Lr, W, p - 1));
+  const float lb = 0.5f * (l + row_at(Lr, W, p + 1));
+  const float ra = 0.5f * (r + row_at(Rr, W, q - 1));
+  const float rb = 0.5f * (r + row_at(Rr, W, q + 1));
+  const float lmi = fminf(la, fminf(lb, l)), lma = fmaxf(la, fmaxf(lb, l));
+  const float rmi = fminf(ra, fminf(rb, r)), rma = fmaxf(ra, fmaxf(rb, r));
+  const float a = fmaxf(0.0f, fmaxf(l - rma, rmi - l));
+  const float b = fmaxf(0.0f, fmaxf(r - lma, lmi - r));
+  return b < a ? b : a;
+}
+
+int orc_birchfield_ex_f32(const float *L, const float *R, float *C, int H, int W,
+                          int D, int padded) {
   if (!L || !R || !C || H <= 0 || W <= 0 || D <= 0) return ORC_EINVAL;
   const int K = 4;
   const size_t n = (size_t)H * W;
@@ -144,15 +165,24 @@ int orc_birchfield_f32(const float *L, const float *R, float *C, int H, int W,
         const int end = imin(W, x + K);
         float cost = 0.0f;
         for (int p = start; p < end; ++p) {
-          const size_t lbase = (size_t)y * W + (size_t)p + 1;
-          const size_t rbase = (size_t)y * W + (size_t)(p - disp) + 1;
-          cost = cost + bt_term(L, R, n, lbase, rbase);
+          if (padded) {
+            cost = cost + bt_term_padded(L + (size_t)y * W, R + (size_t)y * W, W, p, p - disp);
+          } else {
+            const size_t lbase = (size_t)y * W + (size_t)p + 1;
+            const size_t rbase = (size_t)y * W + (size_t)(p - disp) + 1;
+            cost = cost + bt_term(L, R, n, lbase, rbase);
+          }
         }
         out[disp] = cost;
       }
     }
   }
   return ORC_OK;
+}
+
+int orc_birchfield_f32(const float *L, const float *R, float *C, int H, int W,
+                       int D) {
+  return orc_birchfield_ex_f32(L, R, C, H, W, D, 0);
 }
 
 /* ------------------------------------------------------------------------

@@ -47,6 +47,19 @@ __device__ __forceinline__ float4 bt_record(const float *__restrict__ img, long 
   return make_float4(v, fminf(a, fminf(b, v)), fmaxf(a, fmaxf(b, v)), 0.0f);
 }
 
+// {centre, min, max} with the CUDA functor's indexing (src/birchfield_cost.cu:92-139): the
+// sample is row[p], its neighbours row[p-1] and row[p+1], zero outside the row -- what the
+// CPU functor was evidently meant to compute (STM_BT_PADDED, an opt-in extension).
+__device__ __forceinline__ float4 bt_record_padded(const float *__restrict__ row, int W, int p) {
+  const float v = (p >= 0 && p < W) ? row[p] : 0.0f;
+  const float lo = (p - 1 >= 0 && p - 1 < W) ? row[p - 1] : 0.0f;
+  const float hi = (p + 1 >= 0 && p + 1 < W) ? row[p + 1] : 0.0f;
+  const float a = 0.5f * (v + lo);
+  const float b = 0.5f * (v + hi);
+  return make_float4(v, fminf(a, fminf(b, v)), fmaxf(a, fmaxf(b, v)), 0.0f);
+}
+
+template <bool PADDED>
 __global__ __launch_bounds__(kBtBlock) void birchfield_kernel(const float *__restrict__ L_all,
                                                               const float *__restrict__ R_all,
                                                               float *__restrict__ C_all,
@@ -64,11 +77,13 @@ __global__ __launch_bounds__(kBtBlock) void birchfield_kernel(const float *__res
 
   for (int i = threadIdx.x; i < S.ln; i += kBtBlock) {
     const int p = x0 - kBtK + i;
-    Ls[i] = p >= 0 ? bt_record(L, npix, (long)y * S.W + p + 1) : make_float4(0, 0, 0, 0);
+    if (PADDED) Ls[i] = bt_record_padded(L + (size_t)y * S.W, S.W, p);
+    else Ls[i] = p >= 0 ? bt_record(L, npix, (long)y * S.W + p + 1) : make_float4(0, 0, 0, 0);
   }
   for (int i = threadIdx.x; i < S.rn; i += kBtBlock) {
     const int q = x0 - kBtK - (S.D - 1) + i;
-    Rs[i] = q >= 0 ? bt_record(R, npix, (long)y * S.W + q + 1) : make_float4(0, 0, 0, 0);
+    if (PADDED) Rs[i] = bt_record_padded(R + (size_t)y * S.W, S.W, q);
+    else Rs[i] = q >= 0 ? bt_record(R, npix, (long)y * S.W + q + 1) : make_float4(0, 0, 0, 0);
   }
   __syncthreads();
 
@@ -112,6 +127,11 @@ __global__ __launch_bounds__(kBtBlock) void birchfield_kernel(const float *__res
 
 extern "C" int stm_birchfield_f32(const float *left, const float *right, float *cost, int H,
                                   int W, int D, int batch, void *stream) {
+  return stm_birchfield_ex_f32(left, right, cost, H, W, D, 0, batch, stream);
+}
+
+extern "C" int stm_birchfield_ex_f32(const float *left, const float *right, float *cost, int H,
+                                     int W, int D, int flags, int batch, void *stream) {
   using namespace stm;
   STM_REQUIRE(left && right && cost, STM_EINVAL, "stm_birchfield_f32: null pointer");
   STM_REQUIRE(H > 0 && W > 0 && D > 0 && batch > 0, STM_EINVAL,
@@ -127,6 +147,9 @@ extern "C" int stm_birchfield_f32(const float *left, const float *right, float *
   S.rn = kBtTW + 2 * kBtK + D - 1;
   const size_t lds = sizeof(float4) * (size_t)(S.ln + S.rn);
   const dim3 grid((W + kBtTW - 1) / kBtTW, H, batch), block(kBtBlock);
-  hipLaunchKernelGGL(birchfield_kernel, grid, block, lds, as_stream(stream), left, right, cost, S);
+  if (flags & STM_BT_PADDED)
+    hipLaunchKernelGGL(birchfield_kernel<true>, grid, block, lds, as_stream(stream), left, right, cost, S);
+  else
+    hipLaunchKernelGGL(birchfield_kernel<false>, grid, block, lds, as_stream(stream), left, right, cost, S);
   return check_launch("stm_birchfield_f32");
 }

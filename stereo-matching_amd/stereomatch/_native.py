@@ -21,6 +21,7 @@ STM_SGM_KEEP_SUM = 4
 STM_SGM_FULL_MIN = 8
 STM_SGM_TRUE_PATHS = 16
 STM_DP_MODES = {"reference": 0, "corrected": 1}
+STM_BT_INDEXING = {"reference": 0, "padded": 1}
 
 # name -> (restype, argtypes); every symbol include/stereomatch_hip.h declares.
 _vp, _sz, _i, _f = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_float
@@ -30,6 +31,7 @@ PROTOTYPES = {
     "stm_ssd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "stm_ssd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp]),
     "stm_birchfield_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "stm_birchfield_ex_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "stm_sgm_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "stm_sgm_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _sz, _i, _vp]),
     "stm_sgm_wta_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _sz, _i, _vp]),

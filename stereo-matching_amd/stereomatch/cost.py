@@ -84,9 +84,14 @@ class Birchfield:
     they read as 0, a reused one keeps its previous contents there.
     """
 
-    def __init__(self, max_disparity: int, kernel_size: int = 7):
+    def __init__(self, max_disparity: int, kernel_size: int = 7, indexing: str = "reference"):
+        if indexing not in _native.STM_BT_INDEXING:
+            raise ValueError("Birchfield indexing must be one of %s" % sorted(_native.STM_BT_INDEXING))
         self.max_disparity = max_disparity
         self.kernel_size = kernel_size
+        # "reference": the CPU functor's shifted flat indexing (the parity target);
+        # "padded": the CUDA functor's (sample p with zero row borders) -- an opt-in correction.
+        self.indexing = indexing
 
     def __call__(self, left_image: torch.Tensor, right_image: torch.Tensor,
                  cost_volume: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -101,7 +106,8 @@ class Birchfield:
         left = left_image.float().contiguous()
         right = right_image.float().contiguous()
         with torch.cuda.device(device):
-            _native.check(_native.lib().stm_birchfield_f32(
+            _native.check(_native.lib().stm_birchfield_ex_f32(
                 left.data_ptr(), right.data_ptr(), cost_volume.data_ptr(), height, width,
-                self.max_disparity, batch, _native.stream_ptr(device)))
+                self.max_disparity, _native.STM_BT_INDEXING[self.indexing], batch,
+                _native.stream_ptr(device)))
         return cost_volume

@@ -542,3 +542,16 @@ def test_batched_sgm_with_rewalked_diagonals(device, oracle, H, W):
     _, disp = stereomatch.aggregation.Semiglobal().aggregate_and_reduce(_gpu(C, device), _gpu(image, device))
     for b in range(B):
         assert_same_bits(disp[b].cpu().numpy(), oracle.wta(oracle.sgm(C[b], image[b])), "batched fused")
+
+
+@pytest.mark.parametrize("H,W,D", [(24, 40, 16), (7, 200, 128), (5, 70, 256), (9, 50, 20), (3, 3, 64)])
+@pytest.mark.parametrize("kind", ["u8", "unit"])
+def test_birchfield_padded_indexing_matches_oracle(device, oracle, H, W, D, kind):
+    """Opt-in correction: the CUDA functor's sample indexing (src/birchfield_cost.cu:92-139)."""
+    import stereomatch
+    L, R = oracle.synthetic_pair(H, W, seed=3 + D, kind=kind)
+    want = oracle.birchfield(L, R, D, padded=True)
+    got = stereomatch.cost.Birchfield(D, indexing="padded")(_gpu(L, device), _gpu(R, device))
+    assert_same_bits(got.cpu().numpy(), want, "birchfield padded")
+    if W > 8:
+        assert not np.array_equal(want, oracle.birchfield(L, R, D))
