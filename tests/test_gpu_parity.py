@@ -555,3 +555,32 @@ def test_birchfield_padded_indexing_matches_oracle(device, oracle, H, W, D, kind
     assert_same_bits(got.cpu().numpy(), want, "birchfield padded")
     if W > 8:
         assert not np.array_equal(want, oracle.birchfield(L, R, D))
+
+
+def test_evaluation_over_a_synthetic_middlebury_tree(device, oracle, tmp_path):
+    """The evaluation driver (upstream workflows/evaluation/workflow.py) on two synthetic
+    scenes with constant true disparity 7: metrics equal those computed from the oracle's maps."""
+    from PIL import Image
+    from stereomatch.data import MiddleburyDataset, disparity_metrics, write_pfm
+    from stereomatch.evaluation import evaluate_dataset, to_markdown
+    H, W, ndisp = 40, 72, 30          # ndisp 30 -> D = 32; D <= H <= W for the reference DP
+    for s in range(2):
+        d = tmp_path / ("scene%d" % s)
+        d.mkdir()
+        L, R = oracle.synthetic_pair(H, W, seed=s)
+        Image.fromarray(np.stack([L] * 3, axis=-1).astype(np.uint8)).save(d / "im0.png")
+        Image.fromarray(np.stack([R] * 3, axis=-1).astype(np.uint8)).save(d / "im1.png")
+        write_pfm(d / "disp0.pfm", np.full((H, W), 7.0, dtype=np.float32))
+        (d / "calib.txt").write_text("width=%d\nheight=%d\nndisp=%d\n" % (W, H, ndisp))
+    ds = MiddleburyDataset(str(tmp_path))
+    rows = evaluate_dataset(ds, device=str(device))
+    assert [r["pipeline"] for r in rows] == ["ssd-wta-None", "ssd-dyn-None", "ssd-dyn-sgm"]
+    # Independent expectation for the first configuration from the oracle.
+    want = 0.0
+    for s in range(2):
+        L, R = oracle.synthetic_pair(H, W, seed=s)
+        grey = lambda a: (0.2989 * a + 0.587 * a + 0.114 * a).astype(np.float32)
+        disp = oracle.wta(oracle.ssd(grey(L), grey(R), 32, 7))
+        want += disparity_metrics(disp, np.full((H, W), 7.0), bad_thresholds=(2.0,))["rmse"]
+    assert abs(rows[0]["rmse"] - want / 2) < 1e-9
+    assert "ssd-dyn-sgm" in to_markdown(rows)
