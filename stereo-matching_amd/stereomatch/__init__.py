@@ -8,7 +8,8 @@ PyTorch-ROCm device tensors; the arithmetic runs in ``libstereomatch_hip.so``
 (hand-written HIP for gfx950, C ABI in ``include/stereomatch_hip.h``).  There is no
 CPU fallback: CPU tensors raise ``RuntimeError``.
 """
-from . import aggregation, cost, disparity_reduce, distributed, numeric, pipeline  # noqa: F401
+from . import (aggregation, cost, cuda_texture, disparity_reduce, distributed, numeric,  # noqa: F401
+               pipeline)
 from .pipeline import Pipeline  # noqa: F401
 
 __all__ = ["aggregation", "cost", "disparity_reduce", "distributed", "numeric", "pipeline",

@@ -28,3 +28,20 @@ def output_tensor(shape: Sequence[int], dtype: torch.dtype, device: torch.device
     if zero_fresh:
         return torch.zeros(tuple(shape), dtype=dtype, device=device)
     return torch.empty(tuple(shape), dtype=dtype, device=device)
+
+
+def empty_tensor(*sizes, dtype: torch.dtype = torch.float32,
+                 reuse_tensor: Optional[torch.Tensor] = None,
+                 device: torch.device = torch.device("cpu")) -> torch.Tensor:
+    """Upstream-named entry point (``_common.py:15-33``): ``reuse_tensor`` when compatible,
+    else an uninitialised tensor of the given shape."""
+    return output_tensor(sizes, dtype, torch.device(device), reuse=reuse_tensor)
+
+
+def zeros_tensor_like(base_tensor: torch.Tensor,
+                      reuse_tensor: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Upstream-named entry point (``_common.py:36-53``): a zero-filled tensor like
+    ``base_tensor``; a compatible ``reuse_tensor`` is zeroed in place and returned."""
+    if is_reusable(reuse_tensor, base_tensor.shape, base_tensor.dtype, base_tensor.device):
+        return reuse_tensor.zero_()
+    return torch.zeros_like(base_tensor)

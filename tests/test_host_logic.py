@@ -187,3 +187,16 @@ def test_middlebury_reader_and_metrics(tmp_path):
     assert m["bad1"] == 100.0 and m["bad2"] == 0.0
     with pytest.raises(RuntimeError):
         MiddleburyDataset(str(tmp_path / "nope"))
+
+
+def test_upstream_named_helpers_and_texture_placeholder():
+    import stereomatch
+    from stereomatch._common import empty_tensor, zeros_tensor_like
+    buf = torch.ones(2, 3)
+    assert empty_tensor(2, 3, reuse_tensor=buf) is buf
+    assert empty_tensor(2, 4, dtype=torch.int32).shape == (2, 4)
+    z = zeros_tensor_like(torch.ones(2, 3), reuse_tensor=buf)
+    assert z is buf and float(buf.sum()) == 0.0
+    assert zeros_tensor_like(torch.ones(4)).shape == (4,)
+    with pytest.raises(RuntimeError, match="texture"):
+        stereomatch.cuda_texture.CUDATexture()
