@@ -584,3 +584,10 @@ def test_evaluation_over_a_synthetic_middlebury_tree(device, oracle, tmp_path):
         want += disparity_metrics(disp, np.full((H, W), 7.0), bad_thresholds=(2.0,))["rmse"]
     assert abs(rows[0]["rmse"] - want / 2) < 1e-9
     assert "ssd-dyn-sgm" in to_markdown(rows)
+
+
+@pytest.mark.gpu
+def test_graft_entry_smoke_runs(device):
+    """The driver's round-end smoke() is exercised here so it cannot drift from the ops."""
+    import __graft_entry__ as entry
+    entry.smoke()
