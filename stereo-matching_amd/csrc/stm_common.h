@@ -52,28 +52,76 @@ __device__ __forceinline__ float read_lane(float v, int lane) {
       float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
-// Minimum over the 64 lanes, returned wave-uniform.  NaNs are ignored by
-// fminf (v_min_f32 IEEE semantics); an all-+inf wave gives +inf.
+// v_min_f32 / v_min3_f32 as written: fminf() makes hipcc canonicalise both operands first
+// (a v_max_f32 x, x, x each), which doubles the cost of min-heavy inner loops.  Same
+// instruction, same result: the smaller operand, a NaN only when every operand is one.
+__device__ __forceinline__ float vmin_f32(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmin3_f32(float a, float b, float c) {
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// Value of lane-1 plus `addend` (a VGPR); lane 0 receives +inf.  One v_add_f32_dpp.
+__device__ __forceinline__ float lane_up_add(float v, float addend) {
+  float r;
+  asm("v_mov_b32 %0, 0x7f800000\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf"
+      : "=&v"(r) : "v"(v), "v"(addend));
+  return r;
+}
+// Value of lane+1 plus `addend`; lane 63 receives +inf.
+__device__ __forceinline__ float lane_down_add(float v, float addend) {
+  float r;
+  asm("v_mov_b32 %0, 0x7f800000\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf"
+      : "=&v"(r) : "v"(v), "v"(addend));
+  return r;
+}
+
+// Minimum over the 64 lanes, returned wave-uniform.  NaNs are ignored (v_min_f32 IEEE
+// semantics); an all-+inf or all-NaN wave gives +inf.  Six v_min_f32_dpp in place: a lane whose DPP
+// source does not exist (bound_ctrl off) is skipped and keeps its value.  The s_nop 1 in
+// front of each covers the two wait states a DPP read needs after a VALU write of the same
+// register (the assembler does not insert them inside inline asm).
 __device__ __forceinline__ float wave_min_f32(float v) {
-  const float inf = __builtin_inff();
-  v = fminf(v, dpp_f32<0x111>(inf, v));             // row_shr:1
-  v = fminf(v, dpp_f32<0x112>(inf, v));             // row_shr:2
-  v = fminf(v, dpp_f32<0x114>(inf, v));             // row_shr:4
-  v = fminf(v, dpp_f32<0x118>(inf, v));             // row_shr:8  -> lane 15 of each row
-  v = fminf(v, dpp_f32<0x142, 0xa>(inf, v));        // row_bcast:15 into rows 1,3
-  v = fminf(v, dpp_f32<0x143, 0xc>(inf, v));        // row_bcast:31 into rows 2,3
+  asm("s_nop 1\n\t"
+      "v_min_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"  // lane 15 of each row
+      "s_nop 1\n\t"
+      "v_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"  // rows 1, 3
+      "s_nop 1\n\t"
+      "v_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"  // rows 2, 3
+      "v_min_f32 %0, 0x7f800000, %0"  // an all-NaN wave answers +inf, not NaN
+      : "+v"(v));
   return read_lane(v, 63);
 }
 
 __device__ __forceinline__ int wave_min_i32(int v) {
-  const int big = 0x7fffffff;
-  int t;
-  t = dpp_i32<0x111>(big, v); v = t < v ? t : v;
-  t = dpp_i32<0x112>(big, v); v = t < v ? t : v;
-  t = dpp_i32<0x114>(big, v); v = t < v ? t : v;
-  t = dpp_i32<0x118>(big, v); v = t < v ? t : v;
-  t = dpp_i32<0x142, 0xa>(big, v); v = t < v ? t : v;
-  t = dpp_i32<0x143, 0xc>(big, v); v = t < v ? t : v;
+  asm("s_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+      : "+v"(v));
   return __builtin_amdgcn_readlane(v, 63);
 }
 

@@ -155,33 +155,60 @@ __device__ __forceinline__ Walk sgm_decode(int family, int w, int H, int W, bool
   return k;
 }
 
+// P2' of the step between two neighbouring pixels of a path (semiglobal.cpp:137-139):
+// max(P1, P2 / |I(p_i) - I(p_i-1)|).  |a - b| is exactly |b - a|, so a forward and an
+// inverse pass crossing the same pixel boundary use the same value.
+__device__ __forceinline__ float sgm_penalty(float inten, float prev_i, float p1, float p2) {
+  const float q = p2 / fabsf(inten - prev_i);
+  return p1 < q ? q : p1;  // std::max(p1, q)
+}
+
+// A copy of a wave-uniform float that lives in a VGPR (DPP operands must).
+__device__ __forceinline__ float in_vgpr(float x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
 // One step of the recurrence, pixel i-1 -> pixel i of a path (semiglobal.cpp:129-157).
-template <int VPL>
-__device__ __forceinline__ Row<VPL> sgm_step(const Row<VPL> &prev, float prev_i, const Row<VPL> &c,
-                                             float inten, float p1, float p2, int D, int d0,
-                                             int dlim) {
+// p2a: sgm_penalty of the step (wave-uniform); p1v: P1 in a VGPR; drop_tail (VEC only,
+// D = 64 * VPL): this lane's last element is d = D-1 and the reference minimum leaves it out.
+template <int VPL, bool VEC>
+__device__ __forceinline__ Row<VPL> sgm_step(const Row<VPL> &prev, const Row<VPL> &c, float p2a,
+                                             float p1, float p1v, int d0, int dlim,
+                                             bool drop_tail) {
   const float inf = __builtin_inff();
   // m over d in [0, dlim): dlim = D-1 reproduces the reference, whose minimum leaves the
   // element d = D-1 out (Q5); dlim = D is the corrected full-range minimum.
-  float lm = inf;
+  float lm;
+  if constexpr (VEC) {
+    lm = drop_tail ? inf : prev.v[VPL - 1];
 #pragma unroll
-  for (int j = 0; j < VPL; ++j)
-    if (d0 + j < dlim) lm = fminf(lm, prev.v[j]);
+    for (int j = 0; j + 1 < VPL - 1; j += 2) lm = vmin3_f32(lm, prev.v[j], prev.v[j + 1]);
+    if constexpr (VPL % 2 == 0) lm = vmin_f32(lm, prev.v[VPL - 2]);
+  } else {
+    lm = inf;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j)
+      if (d0 + j < dlim) lm = vmin_f32(lm, prev.v[j]);
+  }
   float m = wave_min_f32(lm);
-  if (dlim == 0) m = read_lane(prev.v[0], 0);  // D = 1: empty range, *end() is element D-1
-  const float q = p2 / fabsf(inten - prev_i);
-  const float p2a = p1 < q ? q : p1;  // std::max(p1, q)
+  if constexpr (!VEC) {
+    if (dlim == 0) m = read_lane(prev.v[0], 0);  // D = 1: empty range, *end() is element D-1
+  }
   const float far = m + p2a;
-  const float below = lane_up(prev.v[VPL - 1], inf);  // L(d0-1)
-  const float above = lane_down(prev.v[0], inf);      // L(d0+VPL)
+  const float below = lane_up_add(prev.v[VPL - 1], p1v);  // L(d0-1) + P1
+  const float above = lane_down_add(prev.v[0], p1v);      // L(d0+VPL) + P1
+  float w[VPL];
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) w[j] = prev.v[j] + p1;
   Row<VPL> cur;
 #pragma unroll
   for (int j = 0; j < VPL; ++j) {
-    const float lo = (j == 0 ? below : prev.v[j - 1]) + p1;
-    const float hi = (j == VPL - 1 ? above : prev.v[j + 1]) + p1;
+    const float lo = j == 0 ? below : w[j - 1];
+    const float hi = j == VPL - 1 ? above : w[j + 1];
     // get_min (cpp:11-16) is a strict-'<' chain; as a value that is the minimum of the
     // four candidates (v_min3_f32 + v_min_f32).
-    const float t = fminf(fminf(fminf(prev.v[j], lo), hi), far);
+    const float t = vmin_f32(vmin3_f32(prev.v[j], lo, hi), far);
     const float a = c.v[j] + t;
     cur.v[j] = a - m;
   }
@@ -198,7 +225,8 @@ struct Walker {
   float *__restrict__ out;
   float *__restrict__ spill;  // workspace rows of this image, or nullptr
   int D, d0, dlim;
-  float p1, p2;
+  float p1, p2, p1v;
+  bool drop_tail;
   Row<VPL> prev;
   float prev_i;
 
@@ -209,7 +237,8 @@ struct Walker {
   }
 
   __device__ __forceinline__ Row<VPL> advance(const Row<VPL> &c, float inten) const {
-    return sgm_step<VPL>(prev, prev_i, c, inten, p1, p2, D, d0, dlim);
+    return sgm_step<VPL, VEC>(prev, c, sgm_penalty(inten, prev_i, p1, p2), p1, p1v, d0, dlim,
+                              drop_tail);
   }
 
   __device__ __forceinline__ void emit(long q, int i, const Row<VPL> &s, const Row<VPL> &cur,
@@ -326,6 +355,8 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pass_kernel(const float *__rest
   wk.d0 = lane * VPL;
   wk.p1 = P.p1;
   wk.p2 = P.p2;
+  wk.p1v = in_vgpr(P.p1);
+  wk.drop_tail = VEC && lane == kWave - 1 && P.dlim < P.D;
 
   Walk k = sgm_decode(P.family, w, P.H, P.W, P.true_paths != 0);
   if (!wk.spill) k.spill = 0;
@@ -431,36 +462,51 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_ckpt_kernel(const float *__rest
   }
   if (k.len <= 0) return;
   const long step = (long)k.dy * P.W + k.dx;
-  long pix = (long)k.y0 * P.W + k.x0;
+  const long pix0 = (long)k.y0 * P.W + k.x0;
+  long pix = pix0;
   const int last = k.len - 1;
+  const float p1 = P.p1, p2 = P.p2, p1v = in_vgpr(P.p1);
+  const bool drop_tail = VEC && lane == kWave - 1 && P.dlim < D;
+
+  // P2' depends on the image only, so it is taken off the per-step dependency chain:
+  // every 64 steps the lanes gather the 64 intensity pairs of the next block and do the
+  // division once as a vector; a step then costs one v_readlane.  Lane l of `pen` holds
+  // the penalty of step i0 + l (pixel i0+l-1 -> i0+l).
+  float na, nb, pen = 0.0f;
+  auto pen_inputs = [&](int i0) {
+    const int ia = imin(i0 + lane, last);
+    const int ib = imin(i0 + lane > 0 ? i0 + lane - 1 : 0, last);
+    na = image[pix0 + (long)ia * step];
+    nb = image[pix0 + (long)ib * step];
+  };
+  pen_inputs(0);
 
   Row<VPL> cbuf[kPF];
-  float ibuf[kPF];
 #pragma unroll
   for (int u = 0; u < kPF; ++u) {
     const long q = pix + (long)imin(u, last) * step;
     cbuf[u] = load_row<VPL, VEC>(cost, (size_t)q, D, d0);
-    ibuf[u] = image[q];
   }
   Row<VPL> prev = cbuf[0];
-  float prev_i = ibuf[0];
   if (spill) store_row<VPL, VEC>(spill, 0, D, d0, prev);
   for (int base = 0; base < k.len; base += kPF) {
+    if ((base & (kWave - 1)) == 0) {  // kPF divides 64
+      pen = sgm_penalty(na, nb, p1, p2);
+      pen_inputs(base + kWave);
+    }
 #pragma unroll
     for (int u = 0; u < kPF; ++u) {
       const int i = base + u;
       if (i < k.len) {
         const Row<VPL> c = cbuf[u];
-        const float inten = ibuf[u];
         {
           const long q = pix + (long)imin(kPF, last - i) * step;
           cbuf[u] = load_row<VPL, VEC>(cost, (size_t)q, D, d0);
-          ibuf[u] = image[q];
         }
         if (i > 0) {
-          const Row<VPL> cur = sgm_step<VPL>(prev, prev_i, c, inten, P.p1, P.p2, D, d0, P.dlim);
+          const float p2a = read_lane(pen, i & (kWave - 1));
+          const Row<VPL> cur = sgm_step<VPL, VEC>(prev, c, p2a, p1, p1v, d0, P.dlim, drop_tail);
           prev = cur;
-          prev_i = inten;
           if (spill) store_row<VPL, VEC>(spill, (size_t)i, D, d0, cur);
         }
         // State after pixel i = what segment (i+1)/K starts from.
@@ -494,7 +540,8 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
   const float *image = image_all + (size_t)b * npix;
   float *out = out_all + (size_t)b * npix * P.D;
   const int D = P.D, d0 = lane * VPL;
-  const float p1 = P.p1, p2 = P.p2;
+  const float p1 = P.p1, p2 = P.p2, p1v = in_vgpr(P.p1);
+  const bool drop_tail = VEC && lane == kWave - 1 && P.dlim < D;
 
   const Walk F = sgm_decode(sgm_pair_fwd(P.pair), w, P.H, P.W, P.true_paths != 0);
   const Walk I = sgm_decode(sgm_pair_inv(P.pair), w, P.H, P.W, P.true_paths != 0);
@@ -507,7 +554,6 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
   const int nseg = (F.len + K - 1) / K;
 
   Row<VPL> inv_prev;
-  float inv_prev_i = 0.0f;
 #pragma unroll
   for (int j = 0; j < VPL; ++j) inv_prev.v[j] = 0.0f;
 
@@ -515,13 +561,21 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
     const int base = s * K;
     const int n = imin(K, F.len - base);
     Row<VPL> cseg[K], sseg[K], fseg[K];
-    float iseg[K];
     // Bulk loads of the segment: everything a wave needs for K pixels is in flight at once.
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       const long q = pix0 + (long)(base + imin(j, n - 1)) * step;
       cseg[j] = load_row<VPL, VEC>(cost, (size_t)q, D, d0);
-      iseg[j] = image[q];
+    }
+    // Penalties of the K + 1 pixel boundaries the segment touches, one division for all:
+    // lane l holds P2' between pixels base+l-1 and base+l; the forward step into pixel
+    // base+j reads lane j, the inverse step into it (from base+j+1) lane j+1.
+    float pen;
+    {
+      const int l = imin(lane, K);
+      const int ia = imin(base + l, F.len - 1);
+      const int ib = imin(base + l > 0 ? base + l - 1 : 0, F.len - 1);
+      pen = sgm_penalty(image[pix0 + (long)ia * step], image[pix0 + (long)ib * step], p1, p2);
     }
     if constexpr (!FIRST) {
 #pragma unroll
@@ -532,13 +586,10 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
     }
     // Forward values of the segment, from the path start (s = 0) or the checkpoint.
     Row<VPL> fprev;
-    float fprev_i;
     if (s == 0) {
       fprev = cseg[0];
-      fprev_i = iseg[0];
     } else {
       fprev = load_row<VPL, VEC>(ckpt, (size_t)(s - 1), D, d0);
-      fprev_i = image[pix0 + (long)(base - 1) * step];
     }
 #pragma unroll
     for (int j = 0; j < K; ++j) {
@@ -546,9 +597,9 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
         if (s == 0 && j == 0) {
           fseg[0] = cseg[0];
         } else {
-          fseg[j] = sgm_step<VPL>(fprev, fprev_i, cseg[j], iseg[j], p1, p2, D, d0, P.dlim);
+          fseg[j] = sgm_step<VPL, VEC>(fprev, cseg[j], read_lane(pen, j), p1, p1v, d0, P.dlim,
+                                       drop_tail);
           fprev = fseg[j];
-          fprev_i = iseg[j];
         }
       }
     }
@@ -564,10 +615,10 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
           if (s == nseg - 1 && j == n - 1) {
             li = cseg[j];  // first pixel of the inverse pass: L = C
           } else {
-            li = sgm_step<VPL>(inv_prev, inv_prev_i, cseg[j], iseg[j], p1, p2, D, d0, P.dlim);
+            li = sgm_step<VPL, VEC>(inv_prev, cseg[j], read_lane(pen, j + 1), p1, p1v, d0, P.dlim,
+                                    drop_tail);
           }
           inv_prev = li;
-          inv_prev_i = iseg[j];
 #pragma unroll
           for (int e = 0; e < VPL; ++e) o.v[e] = o.v[e] + li.v[e];
           if (spill) store_row<VPL, VEC>(spill, (size_t)(F.len - 1 - (base + j)), D, d0, li);
