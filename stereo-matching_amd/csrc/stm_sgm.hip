@@ -402,7 +402,9 @@ __global__ __launch_bounds__(256) void sgm_repeat_kernel(float *__restrict__ out
 // same registers and writes the finished rows.  Same float operations in the same order as
 // the single passes -> identical bits; traffic 16N for the four checkpoint walks +
 // 8N + 3 x 12N for the pair launches + ~2N of checkpoints = ~62N.
-// K = 64 / VPL pixels keeps the three row arrays at 64 VGPRs each.
+// K = 32 / VPL pixels (at least 4): the segment's cost rows and its sum rows (which become
+// sum + L_F during the rebuild) are 32 VGPRs each; shorter segments lose more to per-segment
+// latency than the extra resident waves win back, longer ones the other way round (measured).
 // =================================================================================
 // Pixels per segment of the paired form.
 __host__ __device__ constexpr int sgm_seg_len(int vpl) {
@@ -560,7 +562,9 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
   for (int s = nseg - 1; s >= 0; --s) {
     const int base = s * K;
     const int n = imin(K, F.len - base);
-    Row<VPL> cseg[K], sseg[K], fseg[K];
+    // sseg: the sum rows on arrival, sum + L_F after the forward rebuild (no third array:
+    // 2 x 32 floats per lane instead of 3 x 32 keeps one more wave per SIMD resident).
+    Row<VPL> cseg[K], sseg[K];
     // Bulk loads of the segment: everything a wave needs for K pixels is in flight at once.
 #pragma unroll
     for (int j = 0; j < K; ++j) {
@@ -594,13 +598,12 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       if (j < n) {
-        if (s == 0 && j == 0) {
-          fseg[0] = cseg[0];
-        } else {
-          fseg[j] = sgm_step<VPL, VEC>(fprev, cseg[j], read_lane(pen, j), p1, p1v, d0, P.dlim,
-                                       drop_tail);
-          fprev = fseg[j];
-        }
+        if (!(s == 0 && j == 0))
+          fprev = sgm_step<VPL, VEC>(fprev, cseg[j], read_lane(pen, j), p1, p1v, d0, P.dlim,
+                                     drop_tail);
+#pragma unroll
+        for (int e = 0; e < VPL; ++e)
+          sseg[j].v[e] = (FIRST ? 0.0f : sseg[j].v[e]) + fprev.v[e];
       }
     }
     // Inverse walk through the same registers, finishing each row.
@@ -609,7 +612,7 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
       if (j < n) {
         Row<VPL> o;
 #pragma unroll
-        for (int e = 0; e < VPL; ++e) o.v[e] = (FIRST ? 0.0f : sseg[j].v[e]) + fseg[j].v[e];
+        for (int e = 0; e < VPL; ++e) o.v[e] = sseg[j].v[e];
         if (add_inv) {
           Row<VPL> li;
           if (s == nseg - 1 && j == n - 1) {

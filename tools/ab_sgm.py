@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""A/B timing of stm_sgm_wta_f32 from two builds of libstereomatch_hip.so in one process
+(any number, alternating, same buffers; ratios are to the first), so that box-to-box variance cancels.  Development tool.
+
+    python tools/ab_sgm.py stereo-matching_amd/stereomatch/libstereomatch_hip.so /path/other.so
+"""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "stereo-matching_amd"))
+import numpy as np
+import torch
+from stereomatch import _native
+
+
+def load(path):
+    h = ctypes.CDLL(os.path.abspath(path))
+    for name, (restype, argtypes) in _native.PROTOTYPES.items():
+        fn = getattr(h, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return h
+
+
+def main():
+    libs = [load(p) for p in sys.argv[1:]]
+    dev = torch.device("cuda:0")
+    out = []
+    for (H, W, D, B) in ((375, 450, 128, 64), (1080, 1920, 256, 4), (375, 450, 128, 1)):
+        g = torch.Generator(device="cpu").manual_seed(1)
+        cost = (torch.rand((B, H, W, D), generator=g) * 50).to(dev)
+        image = torch.randint(0, 255, (B, H, W), generator=g).float().to(dev)
+        disp = [torch.empty((B, H, W), dtype=torch.int32, device=dev) for _ in libs]
+        scratch = torch.empty_like(cost)  # the running sum (scratch in disparity-only mode)
+        n = max(int(l.stm_sgm_workspace_bytes(H, W, D, B, 0)) for l in libs)
+        ws = torch.empty(max(n, 16), dtype=torch.uint8, device=dev)
+        s = torch.cuda.current_stream().cuda_stream
+
+        def run(i):
+            rc = libs[i].stm_sgm_wta_f32(cost.data_ptr(), image.data_ptr(), scratch.data_ptr(),
+                                         disp[i].data_ptr(),
+                                         H, W, D, 0.1, 0.2, 0, ws.data_ptr(), ws.numel(), B, s)
+            assert rc == 0, libs[i].stm_last_error()
+
+        times = [[] for _ in libs]
+        for rep in range(7):
+            for i in range(len(libs)):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                run(i)
+                b.record()
+                torch.cuda.synchronize()
+                if rep:
+                    times[i].append(a.elapsed_time(b))
+        same = all(bool((disp[0] == d).all()) for d in disp[1:])
+        med = [float(np.median(t)) for t in times]
+        out.append("%dx%dx%d B=%d  " % (H, W, D, B) +
+                   "  ".join("%.3f ms (%.3f)" % (m, m / med[0]) for m in med) + "  same=%s" % same)
+        del cost, image, disp, ws, scratch
+        torch.cuda.empty_cache()
+    print("\n".join(out))
+
+
+if __name__ == "__main__":
+    main()
