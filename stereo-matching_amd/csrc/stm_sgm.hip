@@ -41,7 +41,6 @@ namespace {
 
 constexpr int kSgmBlock = 256;
 constexpr int kPF = 4;  // pixels kept in flight per wave
-constexpr int kSegFloats = 32;  // floats per lane one segment row array occupies (K * VPL)
 
 enum Family : int {
   kRight = 0,      // group 1 forward   (1, 0)
@@ -402,13 +401,16 @@ __global__ __launch_bounds__(256) void sgm_repeat_kernel(float *__restrict__ out
 // same registers and writes the finished rows.  Same float operations in the same order as
 // the single passes -> identical bits; traffic 16N for the four checkpoint walks +
 // 8N + 3 x 12N for the pair launches + ~2N of checkpoints = ~62N.
-// K = 32 / VPL pixels (at least 4): the segment's cost rows and its sum rows (which become
-// sum + L_F during the rebuild) are 32 VGPRs each; shorter segments lose more to per-segment
-// latency than the extra resident waves win back, longer ones the other way round (measured).
+// K pixels per segment (sgm_seg_len): the segment's cost rows and its sum rows (which become
+// sum + L_F during the rebuild) are two register arrays of K * VPL floats per lane.
 // =================================================================================
 // Pixels per segment of the paired form.
 __host__ __device__ constexpr int sgm_seg_len(int vpl) {
-  return kSegFloats / vpl > 4 ? kSegFloats / vpl : 4;
+  // floats per lane one of the two segment row arrays occupies (K * VPL): 32 up to D = 128,
+  // 64 above (measured with tools/ab_sgm.py: D = 128 is flat between 32 and 48 and loses at
+  // 64; D = 256 gains 4-6 % from 32 to 64, another 1.5 % at 96 where D = 192 loses 2 %).
+  const int floats = vpl >= 4 ? 64 : 32;
+  return floats / vpl > 4 ? floats / vpl : 4;
 }
 
 struct PairShape {
