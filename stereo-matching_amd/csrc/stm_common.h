@@ -162,7 +162,7 @@ struct Row {
 
 // Loads the VPL disparities of one pixel owned by this lane; lanes/elements past
 // D read as +inf so that they never win a minimum.
-template <int VPL, bool VEC>
+template <int VPL, bool VEC, bool NT = false>
 __device__ __forceinline__ Row<VPL> load_row(const float *__restrict__ base, size_t pix,
                                               int D, int d0) {
   Row<VPL> r;
@@ -171,11 +171,17 @@ __device__ __forceinline__ Row<VPL> load_row(const float *__restrict__ base, siz
     if constexpr (VPL % 4 == 0) {
 #pragma unroll
       for (int j = 0; j < VPL; j += 4) {
-        const float4 q = *reinterpret_cast<const float4 *>(p + j);
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        v4f q;
+        if constexpr (NT) q = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p + j));
+        else q = *reinterpret_cast<const v4f *>(p + j);
         r.v[j] = q.x; r.v[j + 1] = q.y; r.v[j + 2] = q.z; r.v[j + 3] = q.w;
       }
     } else if constexpr (VPL == 2) {
-      const float2 q = *reinterpret_cast<const float2 *>(p);
+      typedef float v2f __attribute__((ext_vector_type(2)));
+      v2f q;
+      if constexpr (NT) q = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p));
+      else q = *reinterpret_cast<const v2f *>(p);
       r.v[0] = q.x; r.v[1] = q.y;
     } else {
       r.v[0] = p[0];
@@ -187,17 +193,24 @@ __device__ __forceinline__ Row<VPL> load_row(const float *__restrict__ base, siz
   return r;
 }
 
-template <int VPL, bool VEC>
+template <int VPL, bool VEC, bool NT = false>
 __device__ __forceinline__ void store_row(float *__restrict__ base, size_t pix, int D, int d0,
                                           const Row<VPL> &r) {
   float *p = base + pix * (size_t)D + d0;
   if constexpr (VEC) {
     if constexpr (VPL % 4 == 0) {
 #pragma unroll
-      for (int j = 0; j < VPL; j += 4)
-        *reinterpret_cast<float4 *>(p + j) = make_float4(r.v[j], r.v[j + 1], r.v[j + 2], r.v[j + 3]);
+      for (int j = 0; j < VPL; j += 4) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        v4f q; q.x = r.v[j]; q.y = r.v[j + 1]; q.z = r.v[j + 2]; q.w = r.v[j + 3];
+        if constexpr (NT) __builtin_nontemporal_store(q, reinterpret_cast<v4f *>(p + j));
+        else *reinterpret_cast<v4f *>(p + j) = q;
+      }
     } else if constexpr (VPL == 2) {
-      *reinterpret_cast<float2 *>(p) = make_float2(r.v[0], r.v[1]);
+      typedef float v2f __attribute__((ext_vector_type(2)));
+      v2f q; q.x = r.v[0]; q.y = r.v[1];
+      if constexpr (NT) __builtin_nontemporal_store(q, reinterpret_cast<v2f *>(p));
+      else *reinterpret_cast<v2f *>(p) = q;
     } else {
       p[0] = r.v[0];
     }

@@ -525,7 +525,13 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_ckpt_kernel(const float *__rest
 // FINAL (last pair only): 0 = write the finished sum rows; 1 = also reduce every finished
 // row to its first-minimum disparity (the winner-takes-all of src/winners_take_all.cu:21-40,
 // fused so the sum is not re-read); 2 = disparity only, the finished sum is never written.
-template <int VPL, bool VEC, bool FIRST, int FINAL>
+// NT: the segment's cost and sum rows are loaded, and the finished rows stored, with the
+// non-temporal hint.  Every byte is touched once per launch, so on volumes larger than the
+// 256 MiB Infinity Cache keeping them out of it is worth 1.5-6 % (measured, tools/ab_sgm.py);
+// a single Teddy pair (cost + sum = 172 MB) is 4 % faster cached, hence the switch.  The
+// checkpoint walk always loads cached: its four direction families re-read each other's
+// lines (+9 % on Teddy batches with the hint).
+template <int VPL, bool VEC, bool FIRST, int FINAL, bool NT>
 __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__restrict__ cost_all,
                                                              const float *__restrict__ image_all,
                                                              float *__restrict__ out_all,
@@ -571,7 +577,7 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       const long q = pix0 + (long)(base + imin(j, n - 1)) * step;
-      cseg[j] = load_row<VPL, VEC>(cost, (size_t)q, D, d0);
+      cseg[j] = load_row<VPL, VEC, NT>(cost, (size_t)q, D, d0);
     }
     // Penalties of the K + 1 pixel boundaries the segment touches, one division for all:
     // lane l holds P2' between pixels base+l-1 and base+l; the forward step into pixel
@@ -587,7 +593,7 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
 #pragma unroll
       for (int j = 0; j < K; ++j) {
         const long q = pix0 + (long)(base + imin(j, n - 1)) * step;
-        sseg[j] = load_row<VPL, VEC>(out, (size_t)q, D, d0);
+        sseg[j] = load_row<VPL, VEC, NT>(out, (size_t)q, D, d0);
       }
     }
     // Forward values of the segment, from the path start (s = 0) or the checkpoint.
@@ -631,7 +637,7 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
         const long q = pix0 + (long)(base + j) * step;
         // (The re-walked diagonal keeps its rows even in disparity-only mode: the repeat
         // kernel finishes them.)
-        if (FINAL != 2 || spill) store_row<VPL, VEC>(out, (size_t)q, D, d0, o);
+        if (FINAL != 2 || spill) store_row<VPL, VEC, NT>(out, (size_t)q, D, d0, o);
         if constexpr (FINAL != 0) {
           // Strict-'<' scan in register order, then lowest index among the lanes that hold
           // the wave minimum; a NaN at d = 0 wins, as in the reference scan.
@@ -782,12 +788,18 @@ int launch_ckpt(const float *cost, const float *image, float *ws, const PairShap
 
 template <int VPL>
 int launch_pair(const float *cost, const float *image, float *out, float *ws, int32_t *disp,
-                const PairShape &P, bool vec, bool first, int final_mode, hipStream_t s) {
+                const PairShape &P, bool vec, bool first, int final_mode, bool nt, hipStream_t s) {
   const long waves = (long)P.paths[P.pair] * P.batch;
   const dim3 grid((unsigned)((waves + kSgmBlock / kWave - 1) / (kSgmBlock / kWave))), block(kSgmBlock);
-#define STM_PAIR(VEC_, FIRST_, FINAL_)                                                         \
-  hipLaunchKernelGGL((sgm_pair_kernel<VPL, VEC_, FIRST_, FINAL_>), grid, block, 0, s, cost, image, \
-                     out, ws, disp, P)
+#define STM_PAIR(VEC_, FIRST_, FINAL_)                                                          \
+  do {                                                                                          \
+    if (VEC_ && nt)                                                                             \
+      hipLaunchKernelGGL((sgm_pair_kernel<VPL, VEC_, FIRST_, FINAL_, VEC_>), grid, block, 0, s, \
+                         cost, image, out, ws, disp, P);                                        \
+    else                                                                                        \
+      hipLaunchKernelGGL((sgm_pair_kernel<VPL, VEC_, FIRST_, FINAL_, false>), grid, block, 0,   \
+                         s, cost, image, out, ws, disp, P);                                     \
+  } while (0)
   if (final_mode == 1) { if (vec) STM_PAIR(true, false, 1); else STM_PAIR(false, false, 1); }
   else if (final_mode == 2) { if (vec) STM_PAIR(true, false, 2); else STM_PAIR(false, false, 2); }
   else if (vec && first) STM_PAIR(true, true, 0);
@@ -852,6 +864,8 @@ static int sgm_run(const float *cost, const float *left, float *out, int32_t *di
       default: rc = launch_ckpt<16>(cost, left, ws, P, vec, s); break;
     }
     if (rc != STM_OK) return rc;
+    // Cost + sum beyond the Infinity Cache: stream them past it (see sgm_pair_kernel).
+    const bool nt = 2.0 * sizeof(float) * (double)batch * H * W * D > 256.0 * 1024 * 1024;
     for (int pair = 0; pair < 4; ++pair) {
       P.pair = pair;
       const bool first = pair == 0 && !accumulate;
@@ -864,11 +878,11 @@ static int sgm_run(const float *cost, const float *left, float *out, int32_t *di
         if (rc != STM_OK) return rc;
       }
       switch (VPL) {
-        case 1: rc = launch_pair<1>(cost, left, out, ws, disp, P, vec, first, fm, s); break;
-        case 2: rc = launch_pair<2>(cost, left, out, ws, disp, P, vec, first, fm, s); break;
-        case 4: rc = launch_pair<4>(cost, left, out, ws, disp, P, vec, first, fm, s); break;
-        case 8: rc = launch_pair<8>(cost, left, out, ws, disp, P, vec, first, fm, s); break;
-        default: rc = launch_pair<16>(cost, left, out, ws, disp, P, vec, first, fm, s); break;
+        case 1: rc = launch_pair<1>(cost, left, out, ws, disp, P, vec, first, fm, nt, s); break;
+        case 2: rc = launch_pair<2>(cost, left, out, ws, disp, P, vec, first, fm, nt, s); break;
+        case 4: rc = launch_pair<4>(cost, left, out, ws, disp, P, vec, first, fm, nt, s); break;
+        case 8: rc = launch_pair<8>(cost, left, out, ws, disp, P, vec, first, fm, nt, s); break;
+        default: rc = launch_pair<16>(cost, left, out, ws, disp, P, vec, first, fm, nt, s); break;
       }
       if (rc != STM_OK) return rc;
       if (pair == 2 && quirk.wide_extra > 0)

@@ -29,7 +29,11 @@ def main():
     libs = [load(p) for p in sys.argv[1:]]
     dev = torch.device("cuda:0")
     out = []
-    for (H, W, D, B) in ((375, 450, 128, 64), (1080, 1920, 256, 4), (375, 450, 128, 1), (1080, 1920, 256, 1), (540, 960, 192, 8)):
+    sizes = ((375, 450, 128, 64), (1080, 1920, 256, 4), (375, 450, 128, 1), (1080, 1920, 256, 1),
+             (540, 960, 192, 8))
+    if os.environ.get("AB_SIZES"):  # "H,W,D,B;H,W,D,B;..."
+        sizes = tuple(tuple(int(v) for v in t.split(",")) for t in os.environ["AB_SIZES"].split(";"))
+    for (H, W, D, B) in sizes:
         g = torch.Generator(device="cpu").manual_seed(1)
         cost = (torch.rand((B, H, W, D), generator=g) * 50).to(dev)
         image = torch.randint(0, 255, (B, H, W), generator=g).float().to(dev)
