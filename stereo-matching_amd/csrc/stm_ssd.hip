@@ -424,7 +424,14 @@ __device__ __forceinline__ void slide_step(float (&V)[kSlideNV], const SlideRow 
   }
 }
 
-template <bool EDGE>
+// NT: volumes that will not stay in the Infinity Cache anyway are stored past it.
+template <bool NT>
+__device__ __forceinline__ void slide_store(float *p, float v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
+template <bool EDGE, bool NT>
 __device__ __forceinline__ void slide_band(const float *__restrict__ L, const float *__restrict__ R,
                                            float *__restrict__ C, const SlideShape &S, int c0,
                                            int d0, int d, int lane, int r_begin, int r_end,
@@ -462,11 +469,11 @@ __device__ __forceinline__ void slide_band(const float *__restrict__ L, const fl
       for (int ci = 0; ci < kSlideCW; ++ci) {
         if (ci > 0) acc = (acc - V[ci - 1]) + V[ci + 2 * kSlideK - 1];
         if (!EDGE) {
-          out[(size_t)ci * S.D] = acc;
+          slide_store<NT>(out + (size_t)ci * S.D, acc);
         } else if (c0 + ci < W) {
           int dd = d;
           asm volatile("" : "+v"(dd));  // as above: no hoisted lane masks
-          out[(size_t)ci * S.D] = dd <= c0 + ci ? acc : inf;
+          slide_store<NT>(out + (size_t)ci * S.D, dd <= c0 + ci ? acc : inf);
         }
       }
     }
@@ -475,6 +482,7 @@ __device__ __forceinline__ void slide_band(const float *__restrict__ L, const fl
 
 // want_box: 1 = this launch computes when BOX is exact, and exits otherwise (AUTO pairs it
 // with an ORDERED launch that makes the opposite decision).
+template <bool NT>
 __global__ __launch_bounds__(256) void ssd_slide_kernel(const float *__restrict__ L_all,
                                                         const float *__restrict__ R_all,
                                                         float *__restrict__ C_all,
@@ -505,9 +513,9 @@ __global__ __launch_bounds__(256) void ssd_slide_kernel(const float *__restrict_
   __shared__ float slide_lds[4][2 * kSlideRW];
   float *lds = slide_lds[threadIdx.x >> 6];
   if (interior)
-    slide_band<false>(L, R, C, S, c0, d0, d, lane, r_begin, r_end, lds);
+    slide_band<false, NT>(L, R, C, S, c0, d0, d, lane, r_begin, r_end, lds);
   else
-    slide_band<true>(L, R, C, S, c0, d0, d, lane, r_begin, r_end, lds);
+    slide_band<true, NT>(L, R, C, S, c0, d0, d, lane, r_begin, r_end, lds);
 }
 
 }  // namespace
@@ -570,8 +578,16 @@ extern "C" int stm_ssd_f32(const float *left, const float *right, float *cost, i
     T.bands = (H + band_h - 1) / band_h;
     const long waves = per_band * T.bands;
     STM_REQUIRE(waves < (1l << 31), STM_EUNSUPPORTED, "stm_ssd_f32: too many strips");
-    hipLaunchKernelGGL(ssd_slide_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, left,
-                       right, cost, ws, T);
+    // Same rule as the aggregation: a volume that a consumer can still find in the 256 MiB
+    // Infinity Cache is stored normally, a larger one with the non-temporal hint (4 % on a
+    // 64-pair Teddy batch).
+    const bool nt = sizeof(float) * (double)batch * H * W * D > 128.0 * 1024 * 1024;
+    if (nt)
+      hipLaunchKernelGGL(ssd_slide_kernel<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s,
+                         left, right, cost, ws, T);
+    else
+      hipLaunchKernelGGL(ssd_slide_kernel<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s,
+                         left, right, cost, ws, T);
     int rc = check_launch("stm_ssd_f32 (slide)");
     if (rc != STM_OK) return rc;
     if (mode == STM_SSD_BOX) return STM_OK;

@@ -43,7 +43,21 @@ def main():
         ws = torch.empty(max(n, 16), dtype=torch.uint8, device=dev)
         s = torch.cuda.current_stream().cuda_stream
 
+        op = os.environ.get("AB_OP", "sgm_wta")
+        if op == "ssd":
+            left = torch.randint(0, 255, (B, H, W), generator=g).float().to(dev)
+            right = torch.randint(0, 255, (B, H, W), generator=g).float().to(dev)
+
         def run(i):
+            if op == "ssd":  # AUTO mode on integer images: classifier + sliding BOX kernel
+                rc = libs[i].stm_ssd_f32(left.data_ptr(), right.data_ptr(), scratch.data_ptr(), H, W,
+                                         D, 7, 0, ws.data_ptr(), ws.numel(), B, s)
+                assert rc == 0, libs[i].stm_last_error()
+                return
+            if op == "wta":
+                rc = libs[i].stm_wta_f32(cost.data_ptr(), disp[i].data_ptr(), H, W, D, B, s)
+                assert rc == 0, libs[i].stm_last_error()
+                return
             rc = libs[i].stm_sgm_wta_f32(cost.data_ptr(), image.data_ptr(), scratch.data_ptr(),
                                          disp[i].data_ptr(),
                                          H, W, D, 0.1, 0.2, 0, ws.data_ptr(), ws.numel(), B, s)
