@@ -66,23 +66,19 @@ __device__ __forceinline__ float vmin3_f32(float a, float b, float c) {
   return r;
 }
 
-// Value of lane-1 plus `addend` (a VGPR); lane 0 receives +inf.  One v_add_f32_dpp.
-__device__ __forceinline__ float lane_up_add(float v, float addend) {
-  float r;
-  asm("v_mov_b32 %0, 0x7f800000\n\t"
-      "s_nop 1\n\t"
+// acc = value of lane-1 plus `addend` (a VGPR), written with one v_add_f32_dpp.  Lane 0 has
+// no source and is skipped (bound_ctrl off), so it keeps what `acc` held: initialise `acc`
+// to +inf once and reuse the same variable for every call, and lane 0 reads +inf for ever.
+__device__ __forceinline__ void lane_up_add(float &acc, float v, float addend) {
+  asm("s_nop 1\n\t"
       "v_add_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf"
-      : "=&v"(r) : "v"(v), "v"(addend));
-  return r;
+      : "+v"(acc) : "v"(v), "v"(addend));
 }
-// Value of lane+1 plus `addend`; lane 63 receives +inf.
-__device__ __forceinline__ float lane_down_add(float v, float addend) {
-  float r;
-  asm("v_mov_b32 %0, 0x7f800000\n\t"
-      "s_nop 1\n\t"
+// acc = value of lane+1 plus `addend`; lane 63 keeps its (+inf) content.
+__device__ __forceinline__ void lane_down_add(float &acc, float v, float addend) {
+  asm("s_nop 1\n\t"
       "v_add_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf"
-      : "=&v"(r) : "v"(v), "v"(addend));
-  return r;
+      : "+v"(acc) : "v"(v), "v"(addend));
 }
 
 // Minimum over the 64 lanes, returned wave-uniform.  NaNs are ignored (v_min_f32 IEEE

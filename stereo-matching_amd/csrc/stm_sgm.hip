@@ -168,19 +168,34 @@ __device__ __forceinline__ float in_vgpr(float x) {
   return x;
 }
 
+// Per-wave constants and scratch of sgm_step.
+struct StepCtx {
+  float p1, p1v;     // P1 as a scalar and as a VGPR copy (DPP operands must be VGPRs)
+  float below, above;  // DPP results; lane 0 of `below` / lane 63 of `above` stay +inf
+  int d0, dlim;
+  bool drop_tail;    // VEC only (D = 64 * VPL): this lane's last element is d = D-1 and the
+                     // reference minimum leaves it out
+  __device__ __forceinline__ void init(float p1_, int d0_, int dlim_, bool drop_tail_) {
+    p1 = p1_;
+    p1v = in_vgpr(p1_);
+    below = above = in_vgpr(__builtin_inff());
+    d0 = d0_;
+    dlim = dlim_;
+    drop_tail = drop_tail_;
+  }
+};
+
 // One step of the recurrence, pixel i-1 -> pixel i of a path (semiglobal.cpp:129-157).
-// p2a: sgm_penalty of the step (wave-uniform); p1v: P1 in a VGPR; drop_tail (VEC only,
-// D = 64 * VPL): this lane's last element is d = D-1 and the reference minimum leaves it out.
+// p2a: sgm_penalty of the step (wave-uniform).
 template <int VPL, bool VEC>
 __device__ __forceinline__ Row<VPL> sgm_step(const Row<VPL> &prev, const Row<VPL> &c, float p2a,
-                                             float p1, float p1v, int d0, int dlim,
-                                             bool drop_tail) {
+                                             StepCtx &X) {
   const float inf = __builtin_inff();
   // m over d in [0, dlim): dlim = D-1 reproduces the reference, whose minimum leaves the
   // element d = D-1 out (Q5); dlim = D is the corrected full-range minimum.
   float lm;
   if constexpr (VEC) {
-    lm = drop_tail ? inf : prev.v[VPL - 1];
+    lm = X.drop_tail ? inf : prev.v[VPL - 1];
 #pragma unroll
     for (int j = 0; j + 1 < VPL - 1; j += 2) lm = vmin3_f32(lm, prev.v[j], prev.v[j + 1]);
     if constexpr (VPL % 2 == 0) lm = vmin_f32(lm, prev.v[VPL - 2]);
@@ -188,23 +203,23 @@ __device__ __forceinline__ Row<VPL> sgm_step(const Row<VPL> &prev, const Row<VPL
     lm = inf;
 #pragma unroll
     for (int j = 0; j < VPL; ++j)
-      if (d0 + j < dlim) lm = vmin_f32(lm, prev.v[j]);
+      if (X.d0 + j < X.dlim) lm = vmin_f32(lm, prev.v[j]);
   }
   float m = wave_min_f32(lm);
   if constexpr (!VEC) {
-    if (dlim == 0) m = read_lane(prev.v[0], 0);  // D = 1: empty range, *end() is element D-1
+    if (X.dlim == 0) m = read_lane(prev.v[0], 0);  // D = 1: empty range, *end() is element D-1
   }
   const float far = m + p2a;
-  const float below = lane_up_add(prev.v[VPL - 1], p1v);  // L(d0-1) + P1
-  const float above = lane_down_add(prev.v[0], p1v);      // L(d0+VPL) + P1
+  lane_up_add(X.below, prev.v[VPL - 1], X.p1v);  // L(d0-1) + P1
+  lane_down_add(X.above, prev.v[0], X.p1v);      // L(d0+VPL) + P1
   float w[VPL];
 #pragma unroll
-  for (int j = 0; j < VPL; ++j) w[j] = prev.v[j] + p1;
+  for (int j = 0; j < VPL; ++j) w[j] = prev.v[j] + X.p1;
   Row<VPL> cur;
 #pragma unroll
   for (int j = 0; j < VPL; ++j) {
-    const float lo = j == 0 ? below : w[j - 1];
-    const float hi = j == VPL - 1 ? above : w[j + 1];
+    const float lo = j == 0 ? X.below : w[j - 1];
+    const float hi = j == VPL - 1 ? X.above : w[j + 1];
     // get_min (cpp:11-16) is a strict-'<' chain; as a value that is the minimum of the
     // four candidates (v_min3_f32 + v_min_f32).
     const float t = vmin_f32(vmin3_f32(prev.v[j], lo, hi), far);
@@ -223,9 +238,9 @@ struct Walker {
   const float *__restrict__ image;
   float *__restrict__ out;
   float *__restrict__ spill;  // workspace rows of this image, or nullptr
-  int D, d0, dlim;
-  float p1, p2, p1v;
-  bool drop_tail;
+  int D, d0;
+  float p1, p2;
+  StepCtx X;
   Row<VPL> prev;
   float prev_i;
 
@@ -235,9 +250,8 @@ struct Walker {
     inten = image[q];
   }
 
-  __device__ __forceinline__ Row<VPL> advance(const Row<VPL> &c, float inten) const {
-    return sgm_step<VPL, VEC>(prev, c, sgm_penalty(inten, prev_i, p1, p2), p1, p1v, d0, dlim,
-                              drop_tail);
+  __device__ __forceinline__ Row<VPL> advance(const Row<VPL> &c, float inten) {
+    return sgm_step<VPL, VEC>(prev, c, sgm_penalty(inten, prev_i, p1, p2), X);
   }
 
   __device__ __forceinline__ void emit(long q, int i, const Row<VPL> &s, const Row<VPL> &cur,
@@ -350,12 +364,10 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pass_kernel(const float *__rest
   wk.out = out_all + (size_t)b * npix * P.D;
   wk.spill = ws_all ? ws_all + (size_t)b * P.ws_rows * P.D : nullptr;
   wk.D = P.D;
-  wk.dlim = P.dlim;
   wk.d0 = lane * VPL;
   wk.p1 = P.p1;
   wk.p2 = P.p2;
-  wk.p1v = in_vgpr(P.p1);
-  wk.drop_tail = VEC && lane == kWave - 1 && P.dlim < P.D;
+  wk.X.init(P.p1, lane * VPL, P.dlim, VEC && lane == kWave - 1 && P.dlim < P.D);
 
   Walk k = sgm_decode(P.family, w, P.H, P.W, P.true_paths != 0);
   if (!wk.spill) k.spill = 0;
@@ -469,8 +481,9 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_ckpt_kernel(const float *__rest
   const long pix0 = (long)k.y0 * P.W + k.x0;
   long pix = pix0;
   const int last = k.len - 1;
-  const float p1 = P.p1, p2 = P.p2, p1v = in_vgpr(P.p1);
-  const bool drop_tail = VEC && lane == kWave - 1 && P.dlim < D;
+  const float p1 = P.p1, p2 = P.p2;
+  StepCtx X;
+  X.init(P.p1, d0, P.dlim, VEC && lane == kWave - 1 && P.dlim < D);
 
   // P2' depends on the image only, so it is taken off the per-step dependency chain:
   // every 64 steps the lanes gather the 64 intensity pairs of the next block and do the
@@ -509,7 +522,7 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_ckpt_kernel(const float *__rest
         }
         if (i > 0) {
           const float p2a = read_lane(pen, i & (kWave - 1));
-          const Row<VPL> cur = sgm_step<VPL, VEC>(prev, c, p2a, p1, p1v, d0, P.dlim, drop_tail);
+          const Row<VPL> cur = sgm_step<VPL, VEC>(prev, c, p2a, X);
           prev = cur;
           if (spill) store_row<VPL, VEC>(spill, (size_t)i, D, d0, cur);
         }
@@ -550,8 +563,9 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
   const float *image = image_all + (size_t)b * npix;
   float *out = out_all + (size_t)b * npix * P.D;
   const int D = P.D, d0 = lane * VPL;
-  const float p1 = P.p1, p2 = P.p2, p1v = in_vgpr(P.p1);
-  const bool drop_tail = VEC && lane == kWave - 1 && P.dlim < D;
+  const float p1 = P.p1, p2 = P.p2;
+  StepCtx X;
+  X.init(P.p1, d0, P.dlim, VEC && lane == kWave - 1 && P.dlim < D);
 
   const Walk F = sgm_decode(sgm_pair_fwd(P.pair), w, P.H, P.W, P.true_paths != 0);
   const Walk I = sgm_decode(sgm_pair_inv(P.pair), w, P.H, P.W, P.true_paths != 0);
@@ -607,8 +621,7 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
     for (int j = 0; j < K; ++j) {
       if (j < n) {
         if (!(s == 0 && j == 0))
-          fprev = sgm_step<VPL, VEC>(fprev, cseg[j], read_lane(pen, j), p1, p1v, d0, P.dlim,
-                                     drop_tail);
+          fprev = sgm_step<VPL, VEC>(fprev, cseg[j], read_lane(pen, j), X);
 #pragma unroll
         for (int e = 0; e < VPL; ++e)
           sseg[j].v[e] = (FIRST ? 0.0f : sseg[j].v[e]) + fprev.v[e];
@@ -626,8 +639,7 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
           if (s == nseg - 1 && j == n - 1) {
             li = cseg[j];  // first pixel of the inverse pass: L = C
           } else {
-            li = sgm_step<VPL, VEC>(inv_prev, cseg[j], read_lane(pen, j + 1), p1, p1v, d0, P.dlim,
-                                    drop_tail);
+            li = sgm_step<VPL, VEC>(inv_prev, cseg[j], read_lane(pen, j + 1), X);
           }
           inv_prev = li;
 #pragma unroll
