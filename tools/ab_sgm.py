@@ -44,6 +44,9 @@ def main():
         s = torch.cuda.current_stream().cuda_stream
 
         op = os.environ.get("AB_OP", "sgm_wta")
+        if op == "dp":
+            dp_path = torch.empty((B, H, W, D), dtype=torch.int8, device=dev)
+            dp_fin = torch.empty((B, H, D), dtype=torch.float32, device=dev)
         if op == "ssd":
             left = torch.randint(0, 255, (B, H, W), generator=g).float().to(dev)
             right = torch.randint(0, 255, (B, H, W), generator=g).float().to(dev)
@@ -52,6 +55,11 @@ def main():
             if op == "ssd":  # AUTO mode on integer images: classifier + sliding BOX kernel
                 rc = libs[i].stm_ssd_f32(left.data_ptr(), right.data_ptr(), scratch.data_ptr(), H, W,
                                          D, 7, 0, ws.data_ptr(), ws.numel(), B, s)
+                assert rc == 0, libs[i].stm_last_error()
+                return
+            if op == "dp":
+                rc = libs[i].stm_dp_f32(cost.data_ptr(), dp_path.data_ptr(), dp_fin.data_ptr(),
+                                        disp[i].data_ptr(), H, W, D, 1, B, s)
                 assert rc == 0, libs[i].stm_last_error()
                 return
             if op == "wta":
