@@ -79,8 +79,11 @@ def main():
                 if cur is None:
                     continue
                 cur["bytes"] += float(r["Counter_Value"]) * 1024.0 * scale
-                if k.startswith("sgm_pair_kernel") and k.endswith(", 2>"):
-                    cur["fused"] = True
+                # sgm_pair_kernel<VPL, VEC, FIRST, FINAL, NT>: FINAL = 2 is the disparity-only form
+                if k.startswith("sgm_pair_kernel"):
+                    args = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")]
+                    if len(args) >= 4 and args[3] == "2":
+                        cur["fused"] = True
             mine = [g for g in groups if g["vpl"].startswith("sgm_ckpt_kernel<%d," % vpl)]
             for kind in (True, False):
                 sel = [g["bytes"] for g in mine if g["fused"] == kind]
