@@ -122,3 +122,30 @@ def test_1080p_sgm_full_volume_matches_oracle(device, oracle):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     assert np.array_equal(disp.cpu().numpy(), oracle.wta(want))
     assert float((disp == 7).float().mean()) > 0.9
+
+
+def test_teddy_batch_takes_the_streaming_variants_and_matches_single_pairs(device, oracle):
+    """A four-pair Teddy batch is past the Infinity-Cache threshold, so SSD stores and the
+    aggregation's segment loads/stores use their non-temporal variants: every pair must still
+    equal its own single-pair run (cached variants), bit for bit, and pair 0 the reference
+    digests."""
+    import stereomatch
+    g = GOLDEN["teddy 375x450x128"]
+    H, W, D = g["H"], g["W"], g["D"]
+    pairs = [oracle.synthetic_pair(H, W, seed=s) for s in range(4)]
+    Lb = torch.from_numpy(np.stack([p[0] for p in pairs])).to(device)
+    Rb = torch.from_numpy(np.stack([p[1] for p in pairs])).to(device)
+    ssd = stereomatch.cost.SSD(D)
+    sgm = stereomatch.aggregation.Semiglobal()
+    wta = stereomatch.disparity_reduce.WinnerTakesAll()
+    Cb = ssd(Lb, Rb)
+    Sb = sgm(Cb, Lb)
+    _, fused_b = sgm.aggregate_and_reduce(Cb, Lb)
+    assert digest16(Cb[0]) == g["ssd"] and digest16(Sb[0]) == g["sgm"]
+    assert digest16(fused_b[0]) == g["ssd_sgm_wta"]
+    for b in range(4):
+        C1 = ssd(Lb[b], Rb[b])
+        assert torch.equal(C1.view(torch.int32), Cb[b].view(torch.int32)), "ssd pair %d" % b
+        S1 = sgm(C1, Lb[b])
+        assert torch.equal(S1.view(torch.int32), Sb[b].view(torch.int32)), "sgm pair %d" % b
+        assert torch.equal(wta(S1), fused_b[b]), "fused pair %d" % b
