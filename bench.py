@@ -182,7 +182,9 @@ def roofline(job, sgm_ms, traffic=None):
                       "(stm_sgm_wta_f32)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "algorithmic_bytes": algorithmic, "ms": round(sgm_ms, 4)}
+            "algorithmic_bytes": algorithmic, "ms": round(sgm_ms, 4),
+            # the rate the counted HBM traffic moves at (not part of the contract's fields)
+            "traffic_rate": None if traffic is None else round(traffic / (sgm_ms * 1e-3) / 1e9, 1)}
 
 
 def load_traffic(name, batch):
