@@ -411,9 +411,12 @@ __device__ __forceinline__ void slide_step(float (&V)[kSlideNV], const SlideRow 
     float qx = dx * dx;
     if (EDGE) {
       const int kc = kc0 + t;
-      const int lim = kc < W ? kc : -1;  // tap inside the window iff d <= kc < W
-      // Keep the compare next to its use: hoisted out of the row loop, the 77 lane masks
-      // would not fit the scalar register file.
+      // Keep the limit and the compare next to their use: both are loop-invariant, and
+      // hoisted out of the row loop the 77 limits and 77 lane masks would not fit the scalar
+      // register file (they were spilled through v_writelane / v_readlane).
+      int w = W;
+      asm volatile("" : "+s"(w));
+      const int lim = kc < w ? kc : -1;  // tap inside the window iff d <= kc < W
       int dd = d;
       asm volatile("" : "+v"(dd));
       const bool in = dd <= lim;
@@ -464,17 +467,28 @@ __device__ __forceinline__ void slide_band(const float *__restrict__ L, const fl
       float acc = 0.0f;
 #pragma unroll
       for (int t = 0; t < 2 * kSlideK; ++t) acc = acc + V[t];
-      float *out = C + ((size_t)r * W + c0) * S.D + d;
+      // Store address = wave-uniform row base (SGPRs) + a 32-bit per-lane byte offset that
+      // advances by one pixel (4*D bytes) per column.  The offset is made opaque after every
+      // step: the 64 column addresses are loop-invariant, and hoisted out of the row loop
+      // they cost 128 SGPRs (spilled lane by lane through v_writelane / v_readlane, which
+      // was most of the kernel's instruction count).
+      char *out_u = reinterpret_cast<char *>(C + ((size_t)r * W + c0) * S.D + d0);
+      unsigned off = 4u * (unsigned)lane;
+      const unsigned pix_bytes = 4u * (unsigned)S.D;
 #pragma unroll
       for (int ci = 0; ci < kSlideCW; ++ci) {
         if (ci > 0) acc = (acc - V[ci - 1]) + V[ci + 2 * kSlideK - 1];
+        float *dst = reinterpret_cast<float *>(out_u + off);
         if (!EDGE) {
-          slide_store<NT>(out + (size_t)ci * S.D, acc);
-        } else if (c0 + ci < W) {
-          int dd = d;
-          asm volatile("" : "+v"(dd));  // as above: no hoisted lane masks
-          slide_store<NT>(out + (size_t)ci * S.D, dd <= c0 + ci ? acc : inf);
+          slide_store<NT>(dst, acc);
+        } else {
+          int w = W, dd = d;
+          asm volatile("" : "+s"(w));
+          asm volatile("" : "+v"(dd));  // as above: nothing hoisted
+          if (c0 + ci < w) slide_store<NT>(dst, dd <= c0 + ci ? acc : inf);
         }
+        off += pix_bytes;
+        asm volatile("" : "+v"(off));
       }
     }
   }
