@@ -417,13 +417,13 @@ __device__ __forceinline__ void slide_step(float (&V)[kSlideNV], const SlideRow 
       int w = W;
       asm volatile("" : "+s"(w));
       const int lim = kc < w ? kc : -1;  // tap inside the window iff d <= kc < W
-      int dd = d;
-      asm volatile("" : "+v"(dd));
-      const bool in = dd <= lim;
-      qe = in ? qe : 0.0f;
-      qx = in ? qx : 0.0f;
+      // One select on the updated sum instead of one on each square: a column outside the
+      // lane's window keeps V[t] (= 0) whatever the staged samples were.
+      const float upd = (V[t] + qe) - qx;
+      V[t] = d <= lim ? upd : V[t];
+    } else {
+      V[t] = (V[t] + qe) - qx;
     }
-    V[t] = (V[t] + qe) - qx;
   }
 }
 
