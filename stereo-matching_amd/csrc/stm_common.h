@@ -189,6 +189,13 @@ __device__ __forceinline__ Row<VPL> load_row(const float *__restrict__ base, siz
   return r;
 }
 
+// The same with the row given as an element offset (a running 64-bit scalar in the callers).
+template <int VPL, bool VEC, bool NT = false>
+__device__ __forceinline__ Row<VPL> load_row_at(const float *__restrict__ base, long off, int D,
+                                                 int d0) {
+  return load_row<VPL, VEC, NT>(base + off, 0, D, d0);
+}
+
 template <int VPL, bool VEC, bool NT = false>
 __device__ __forceinline__ void store_row(float *__restrict__ base, size_t pix, int D, int d0,
                                           const Row<VPL> &r) {
@@ -215,6 +222,12 @@ __device__ __forceinline__ void store_row(float *__restrict__ base, size_t pix, 
     for (int j = 0; j < VPL; ++j)
       if (d0 + j < D) p[j] = r.v[j];
   }
+}
+
+template <int VPL, bool VEC, bool NT = false>
+__device__ __forceinline__ void store_row_at(float *__restrict__ base, long off, int D, int d0,
+                                             const Row<VPL> &r) {
+  store_row<VPL, VEC, NT>(base + off, 0, D, d0, r);
 }
 
 #endif  // __HIPCC__

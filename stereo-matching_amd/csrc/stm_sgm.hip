@@ -34,6 +34,8 @@
 // Bound: HBM.  Per pass 4N bytes of cost are read and 4N (first pass: write
 // only) or 8N bytes of the running sum are moved, N = H*W*D: 92N in total
 // against the algorithmic 8N (read cost once, write sum once).
+#include <type_traits>
+
 #include "stm_common.h"
 
 namespace stm {
@@ -581,17 +583,27 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
 #pragma unroll
   for (int j = 0; j < VPL; ++j) inv_prev.v[j] = 0.0f;
 
-  for (int s = nseg - 1; s >= 0; --s) {
+  // One segment.  FULL (n == K, every segment but possibly the path's last one): no per-pixel
+  // bounds tests and no clamped row indices; row addresses are running 64-bit offsets (two
+  // scalar adds per row).  The scalar unit issues at the VALU's rate, and at D <= 128 the
+  // generic form spent twice as many scalar as vector instructions per step.
+  const long stepD = step * (long)D;  // elements between consecutive pixels of the path
+  auto segment = [&](auto full_tag, const int s) {
+    constexpr bool FULL = decltype(full_tag)::value;
     const int base = s * K;
-    const int n = imin(K, F.len - base);
+    const int n = FULL ? K : imin(K, F.len - base);
+    const long off0 = (pix0 + (long)base * step) * (long)D;  // element offset of pixel `base`
     // sseg: the sum rows on arrival, sum + L_F after the forward rebuild (no third array:
-    // 2 x 32 floats per lane instead of 3 x 32 keeps one more wave per SIMD resident).
+    // 2 x K*VPL floats per lane instead of 3 x keeps one more wave per SIMD resident).
     Row<VPL> cseg[K], sseg[K];
     // Bulk loads of the segment: everything a wave needs for K pixels is in flight at once.
+    {
+      long off = off0;
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-      const long q = pix0 + (long)(base + imin(j, n - 1)) * step;
-      cseg[j] = load_row<VPL, VEC, NT>(cost, (size_t)q, D, d0);
+      for (int j = 0; j < K; ++j) {
+        cseg[j] = load_row_at<VPL, VEC, NT>(cost, off, D, d0);
+        if (FULL || j < n - 1) off += stepD;  // rows past the end re-read the last one
+      }
     }
     // Penalties of the K + 1 pixel boundaries the segment touches, one division for all:
     // lane l holds P2' between pixels base+l-1 and base+l; the forward step into pixel
@@ -604,10 +616,11 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
       pen = sgm_penalty(image[pix0 + (long)ia * step], image[pix0 + (long)ib * step], p1, p2);
     }
     if constexpr (!FIRST) {
+      long off = off0;
 #pragma unroll
       for (int j = 0; j < K; ++j) {
-        const long q = pix0 + (long)(base + imin(j, n - 1)) * step;
-        sseg[j] = load_row<VPL, VEC, NT>(out, (size_t)q, D, d0);
+        sseg[j] = load_row_at<VPL, VEC, NT>(out, off, D, d0);
+        if (FULL || j < n - 1) off += stepD;
       }
     }
     // Forward values of the segment, from the path start (s = 0) or the checkpoint.
@@ -619,8 +632,8 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
     }
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      if (j < n) {
-        if (!(s == 0 && j == 0))
+      if (FULL || j < n) {
+        if (j > 0 || s != 0)
           fprev = sgm_step<VPL, VEC>(fprev, cseg[j], read_lane(pen, j), X);
 #pragma unroll
         for (int e = 0; e < VPL; ++e)
@@ -628,15 +641,17 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
       }
     }
     // Inverse walk through the same registers, finishing each row.
+    long off = off0 + (long)(K - 1) * stepD;  // row K-1; rows j >= n are skipped below
+    long q = pix0 + (long)(base + K - 1) * step;
 #pragma unroll
     for (int j = K - 1; j >= 0; --j) {
-      if (j < n) {
+      if (FULL || j < n) {
         Row<VPL> o;
 #pragma unroll
         for (int e = 0; e < VPL; ++e) o.v[e] = sseg[j].v[e];
         if (add_inv) {
           Row<VPL> li;
-          if (s == nseg - 1 && j == n - 1) {
+          if (j == n - 1 && s == nseg - 1) {
             li = cseg[j];  // first pixel of the inverse pass: L = C
           } else {
             li = sgm_step<VPL, VEC>(inv_prev, cseg[j], read_lane(pen, j + 1), X);
@@ -646,10 +661,9 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
           for (int e = 0; e < VPL; ++e) o.v[e] = o.v[e] + li.v[e];
           if (spill) store_row<VPL, VEC>(spill, (size_t)(F.len - 1 - (base + j)), D, d0, li);
         }
-        const long q = pix0 + (long)(base + j) * step;
         // (The re-walked diagonal keeps its rows even in disparity-only mode: the repeat
         // kernel finishes them.)
-        if (FINAL != 2 || spill) store_row<VPL, VEC, NT>(out, (size_t)q, D, d0, o);
+        if (FINAL != 2 || spill) store_row_at<VPL, VEC, NT>(out, off, D, d0, o);
         if constexpr (FINAL != 0) {
           // Strict-'<' scan in register order, then lowest index among the lanes that hold
           // the wave minimum; a NaN at d = 0 wins, as in the reference scan.
@@ -664,7 +678,14 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
           if (lane == 0) disp_all[(size_t)b * npix + (size_t)q] = (first != first) ? 0 : win;
         }
       }
+      off -= stepD;
+      q -= step;
     }
+  };
+
+  for (int s = nseg - 1; s >= 0; --s) {
+    if (F.len - s * K >= K) segment(std::true_type{}, s);
+    else segment(std::false_type{}, s);
   }
 }
 
