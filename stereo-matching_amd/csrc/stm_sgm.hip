@@ -481,7 +481,6 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_ckpt_kernel(const float *__rest
   if (k.len <= 0) return;
   const long step = (long)k.dy * P.W + k.dx;
   const long pix0 = (long)k.y0 * P.W + k.x0;
-  long pix = pix0;
   const int last = k.len - 1;
   const float p1 = P.p1, p2 = P.p2;
   StepCtx X;
@@ -500,11 +499,16 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_ckpt_kernel(const float *__rest
   };
   pen_inputs(0);
 
+  // Ring slot u holds pixel i with i % kPF == u.  `pf` is the running element offset of the
+  // pixel the next prefetch reads, min(i + kPF, last): two scalar adds per step instead of a
+  // clamped 64-bit multiply.
+  const long stepD = step * (long)D;
+  long pf = pix0 * (long)D;
   Row<VPL> cbuf[kPF];
 #pragma unroll
   for (int u = 0; u < kPF; ++u) {
-    const long q = pix + (long)imin(u, last) * step;
-    cbuf[u] = load_row<VPL, VEC>(cost, (size_t)q, D, d0);
+    cbuf[u] = load_row_at<VPL, VEC>(cost, pf, D, d0);
+    if (u < last) pf += stepD;
   }
   Row<VPL> prev = cbuf[0];
   if (spill) store_row<VPL, VEC>(spill, 0, D, d0, prev);
@@ -518,10 +522,8 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_ckpt_kernel(const float *__rest
       const int i = base + u;
       if (i < k.len) {
         const Row<VPL> c = cbuf[u];
-        {
-          const long q = pix + (long)imin(kPF, last - i) * step;
-          cbuf[u] = load_row<VPL, VEC>(cost, (size_t)q, D, d0);
-        }
+        cbuf[u] = load_row_at<VPL, VEC>(cost, pf, D, d0);
+        if (i + kPF < last) pf += stepD;
         if (i > 0) {
           const float p2a = read_lane(pen, i & (kWave - 1));
           const Row<VPL> cur = sgm_step<VPL, VEC>(prev, c, p2a, X);
@@ -531,7 +533,6 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_ckpt_kernel(const float *__rest
         // State after pixel i = what segment (i+1)/K starts from.
         if (ckpt && ((i + 1) % K) == 0 && i + 1 < k.len)
           store_row<VPL, VEC>(ckpt, (size_t)((i + 1) / K - 1), D, d0, prev);
-        pix += step;
       }
     }
   }
