@@ -669,10 +669,10 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
           // Strict-'<' scan in register order, then lowest index among the lanes that hold
           // the wave minimum; a NaN at d = 0 wins, as in the reference scan.
           float best = __builtin_inff();
-          int idx = d0 < D ? d0 : 0x7fffffff;
+          int idx = (VEC || d0 < D) ? d0 : 0x7fffffff;  // VEC: D = 64 * VPL, every lane is live
 #pragma unroll
           for (int e = 0; e < VPL; ++e)
-            if (d0 + e < D && o.v[e] < best) { best = o.v[e]; idx = d0 + e; }
+            if ((VEC || d0 + e < D) && o.v[e] < best) { best = o.v[e]; idx = d0 + e; }
           const float m = wave_min_f32(best);
           const int win = wave_min_i32(best == m ? idx : 0x7fffffff);
           const float first = read_lane(o.v[0], 0);
