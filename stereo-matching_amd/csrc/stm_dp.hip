@@ -184,6 +184,13 @@ __global__ __launch_bounds__(kDpBlock) void dp_forward_kernel(const float *__res
 // line 4 to 8 times), parked in registers during the block and dropped into a padded LDS
 // tile at its end; the path directions of a block leave as one O-byte store per lane.
 // ---------------------------------------------------------------------------------
+// Value of the lane to the left within the DPP row of 16 (row_ror:1).  Every lane has a
+// source, so there is no "old" value to preserve: one v_mov_b32_dpp, no copy in front of it.
+__device__ __forceinline__ float rot1(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x121, 0xf,
+                                                            0xf, false));
+}
+
 template <int O>
 __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ vol_all,
                                                      int8_t *__restrict__ path_all,
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
         prev = out;
         outs[j] = out;
         pk[j / 4] |= (unsigned)(dir & 0xff) << (8 * (j % 4));
-        hist[j] = dpp_f32<0x121>(out, out);        // row_ror:1 -> the column on the right
+        hist[j] = rot1(out);        // row_ror:1 -> the column on the right
       }
     } else {
       // Steady state.  With m23 = (c2 < c3 ? c2 : c3) the reference's three-way choice is
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
         const int dir = c1 < m23 ? -1 : (c2 < c3 ? 0 : 1);
         outs[j] = out;
         pk[j / 4] |= (unsigned)(dir & 0xff) << (8 * (j % 4));
-        hist[j] = dpp_f32<0x121>(out, out);
+        hist[j] = rot1(out);
         c1 = out;
       }
       prev = c1;
