@@ -201,6 +201,10 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
   constexpr int PPI = 64 / LP;       // pieces per cooperative load instruction
   constexpr int LD = O + 1;          // padded LDS row: conflict-free ds_read_b32 by 64 lanes
   __shared__ float tile[2][64 * LD];
+  // Path bytes of the column each lane is working on (P bytes = P/4 dwords, padded): a
+  // column's record leaves as whole lines once it is complete (see the end of the loop).
+  constexpr int PB = P / 4 + 4;
+  __shared__ __attribute__((aligned(16))) unsigned pbuf[64 * PB];
   __shared__ float init[4][P];
   __shared__ float fin[4][P + 1];
   const int lane = threadIdx.x;
@@ -333,14 +337,33 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
 #pragma unroll
       for (int j = 0; j < O; ++j) fin[rq][isfin ? d0 + j : P] = outs[j];  // slot P: dump
     }
-    if (live) {
-      int8_t *dst = path + ((size_t)row * W + col) * D + d0;
+    // Path directions.  A lane's O bytes of this block are one short piece of a column that
+    // lies 4*D bytes away from its neighbours', so storing them directly costs 64 cache lines
+    // per instruction (measured: more than half of the kernel at D = 128).  Instead they are
+    // collected per column in LDS; in every block exactly four columns (one per image row of
+    // the wave, those of lane (blk + 1) & 15) receive their last piece, and their 4 x P bytes
+    // leave in one instruction, 16 lanes x O bytes per column.
+    {
+      unsigned *mine = &pbuf[lane * PB + (q & 15) * LP];
 #pragma unroll
-      for (int u = 0; u < LP; u += 4) {
-        if (LP >= 4) {
-          *reinterpret_cast<uint4 *>(dst + 4 * u) = make_uint4(pk[u], pk[(u + 1) % LP], pk[(u + 2) % LP], pk[(u + 3) % LP]);
-        } else {
-          *reinterpret_cast<uint2 *>(dst) = make_uint2(pk[0], pk[1 % LP]);
+      for (int u = 0; u < LP; ++u) mine[u] = pk[u];
+      const int vd = (blk + 1) & 15;           // lanes finishing a column in this block
+      const int qd = blk - vd;                 // = 15 (mod 16)
+      const int cd = vd + 16 * (qd >> 4);      // that column (negative before the first one)
+      const int crow = blockIdx.x * 4 + rq;    // this lane serves image row rq, piece v
+      const unsigned *src = &pbuf[(rq * 16 + vd) * PB + v * LP];
+      unsigned out_w[LP];
+#pragma unroll
+      for (int u = 0; u < LP; ++u) out_w[u] = src[u];
+      if (qd >= 0 && cd < W && crow < H && v * O < D) {
+        int8_t *dst = path + ((size_t)crow * W + cd) * D + v * O;
+#pragma unroll
+        for (int u = 0; u < LP; u += 4) {
+          if (LP >= 4) {
+            *reinterpret_cast<uint4 *>(dst + 4 * u) = make_uint4(out_w[u], out_w[(u + 1) % LP], out_w[(u + 2) % LP], out_w[(u + 3) % LP]);
+          } else {
+            *reinterpret_cast<uint2 *>(dst) = make_uint2(out_w[0], out_w[1 % LP]);
+          }
         }
       }
     }
