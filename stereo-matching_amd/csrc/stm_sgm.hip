@@ -490,12 +490,15 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_ckpt_kernel(const float *__rest
   // every 64 steps the lanes gather the 64 intensity pairs of the next block and do the
   // division once as a vector; a step then costs one v_readlane.  Lane l of `pen` holds
   // the penalty of step i0 + l (pixel i0+l-1 -> i0+l).
+  // One gather per block (on vertical and diagonal paths every lane's sample is in another
+  // cache line): the left neighbour's sample is a DPP shift, lane 0 takes the last sample of
+  // the block before.
   float na, nb, pen = 0.0f;
+  na = image[pix0];  // "sample -1" of the first block: pixel 0 itself
   auto pen_inputs = [&](int i0) {
-    const int ia = imin(i0 + lane, last);
-    const int ib = imin(i0 + lane > 0 ? i0 + lane - 1 : 0, last);
-    na = image[pix0 + (long)ia * step];
-    nb = image[pix0 + (long)ib * step];
+    const float carry = read_lane(na, kWave - 1);
+    na = image[pix0 + (long)imin(i0 + lane, last) * step];
+    nb = lane_up(na, carry);
   };
   pen_inputs(0);
 
@@ -611,10 +614,12 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
     // base+j reads lane j, the inverse step into it (from base+j+1) lane j+1.
     float pen;
     {
-      const int l = imin(lane, K);
-      const int ia = imin(base + l, F.len - 1);
-      const int ib = imin(base + l > 0 ? base + l - 1 : 0, F.len - 1);
-      pen = sgm_penalty(image[pix0 + (long)ia * step], image[pix0 + (long)ib * step], p1, p2);
+      // One gather: lane l reads pixel base+l-1 (clamped to the path), its right neighbour's
+      // sample arrives by a DPP shift.
+      const int l = imin(lane, K + 1);
+      const int ig = imin(base + l > 0 ? base + l - 1 : 0, F.len - 1);
+      const float g = image[pix0 + (long)ig * step];
+      pen = sgm_penalty(lane_down(g, g), g, p1, p2);
     }
     if constexpr (!FIRST) {
       long off = off0;
