@@ -39,6 +39,11 @@ def test_fuzz_all_ops(device, oracle, H, W, D):
     bt = stereomatch.cost.Birchfield(D)(Lg, Rg)
     assert_same_bits(bt.cpu().numpy(), oracle.birchfield(L, R, D), "birchfield")
     vol = _random_volume(rng, H, W, D, ["float", "ties", "inf", "last"][int(rng.integers(0, 4))])
+    # Like every volume the cost ops produce, d = 0 is finite at every pixel.  A pixel whose
+    # costs are all +inf makes the reference's recurrence emit inf - inf: NaN and -inf then
+    # spread along every path through it, and which of them lands where depends on how
+    # std::min_element and the '<' chains happen to treat NaN operands.
+    vol[..., 0] = np.where(np.isfinite(vol[..., 0]), vol[..., 0], np.float32(5.0))
     image = rng.integers(0, 4, size=(H, W)).astype(np.float32)
     p1, p2 = float(rng.choice([0.1, 0.5, 2.0])), float(rng.choice([0.2, 3.0, 40.0]))
     paths = ["reference", "hirschmuller"][int(rng.integers(0, 2))]

@@ -15,11 +15,19 @@ def _bits(a):
 
 
 def assert_same_bits(got, want, what=""):
+    """Bit-for-bit equality (so +inf and signed zeros count).  A NaN equals any NaN: which
+    sign and payload an inf - inf produces, and which operand's NaN an addition passes on,
+    are properties of x86 and of gfx950, not of the algorithm."""
     got = np.ascontiguousarray(got)
     want = np.ascontiguousarray(want)
     assert got.shape == want.shape, (what, got.shape, want.shape)
     if not np.array_equal(_bits(got), _bits(want)):
-        bad = np.argwhere(_bits(got) != _bits(want))
+        differ = _bits(got) != _bits(want)
+        if got.dtype == np.float32:
+            differ &= ~(np.isnan(got) & np.isnan(want))
+        if not differ.any():
+            return
+        bad = np.argwhere(differ)
         i = tuple(bad[0])
         raise AssertionError("%s: %d of %d entries differ; first at %s: got %r want %r"
                              % (what, len(bad), got.size, i, got[i], want[i]))
