@@ -82,7 +82,7 @@ __device__ __forceinline__ void lane_down_add(float &acc, float v, float addend)
 }
 
 // Minimum over the 64 lanes, returned wave-uniform.  NaNs are ignored (v_min_f32 IEEE
-// semantics); an all-+inf or all-NaN wave gives +inf.  Six v_min_f32_dpp in place: a lane whose DPP
+// semantics) unless every lane holds one; an all-+inf wave gives +inf.  Six v_min_f32_dpp in place: a lane whose DPP
 // source does not exist (bound_ctrl off) is skipped and keeps its value.  The s_nop 1 in
 // front of each covers the two wait states a DPP read needs after a VALU write of the same
 // register (the assembler does not insert them inside inline asm).
@@ -98,8 +98,7 @@ __device__ __forceinline__ float wave_min_f32(float v) {
       "s_nop 1\n\t"
       "v_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"  // rows 1, 3
       "s_nop 1\n\t"
-      "v_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"  // rows 2, 3
-      "v_min_f32 %0, 0x7f800000, %0"  // an all-NaN wave answers +inf, not NaN
+      "v_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"        // rows 2, 3
       : "+v"(v));
   return read_lane(v, 63);
 }
