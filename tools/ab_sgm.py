@@ -47,7 +47,7 @@ def main():
         if op == "dp":
             dp_path = torch.empty((B, H, W, D), dtype=torch.int8, device=dev)
             dp_fin = torch.empty((B, H, D), dtype=torch.float32, device=dev)
-        if op == "ssd":
+        if op in ("ssd", "bt"):
             left = torch.randint(0, 255, (B, H, W), generator=g).float().to(dev)
             right = torch.randint(0, 255, (B, H, W), generator=g).float().to(dev)
 
@@ -60,6 +60,10 @@ def main():
             if op == "dp":
                 rc = libs[i].stm_dp_f32(cost.data_ptr(), dp_path.data_ptr(), dp_fin.data_ptr(),
                                         disp[i].data_ptr(), H, W, D, 1, B, s)
+                assert rc == 0, libs[i].stm_last_error()
+                return
+            if op == "bt":
+                rc = libs[i].stm_birchfield_f32(left.data_ptr(), right.data_ptr(), scratch.data_ptr(), H, W, D, B, s)
                 assert rc == 0, libs[i].stm_last_error()
                 return
             if op == "wta":
