@@ -572,7 +572,8 @@ extern "C" int stm_ssd_f32(const float *left, const float *right, float *cost, i
     hipLaunchKernelGGL(ssd_class_init_kernel, dim3(1), dim3(1), 0, s, ws);
     const size_t n = (size_t)batch * H * W;
     size_t blocks = (2 * n + 255) / 256;
-    if (blocks > 512) blocks = 512;
+    const size_t cap = n > (4u << 20) ? 2048 : 512;  // one atomic triple per block
+    if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(ssd_classify_kernel, dim3((unsigned)blocks), dim3(256), 0, s, left, right, n, ws);
   }
   // Sliding BOX form: k = 7 and whole 64-disparity chunks.

@@ -47,12 +47,15 @@ def main():
         if op == "dp":
             dp_path = torch.empty((B, H, W, D), dtype=torch.int8, device=dev)
             dp_fin = torch.empty((B, H, D), dtype=torch.float32, device=dev)
+        if op == "ssd_float":
+            left = torch.rand((B, H, W), generator=g).to(dev)
+            right = torch.rand((B, H, W), generator=g).to(dev)
         if op in ("ssd", "bt"):
             left = torch.randint(0, 255, (B, H, W), generator=g).float().to(dev)
             right = torch.randint(0, 255, (B, H, W), generator=g).float().to(dev)
 
         def run(i):
-            if op == "ssd":  # AUTO mode on integer images: classifier + sliding BOX kernel
+            if op in ("ssd", "ssd_float"):  # AUTO mode on integer images: classifier + sliding BOX kernel
                 rc = libs[i].stm_ssd_f32(left.data_ptr(), right.data_ptr(), scratch.data_ptr(), H, W,
                                          D, 7, 0, ws.data_ptr(), ws.numel(), B, s)
                 assert rc == 0, libs[i].stm_last_error()
