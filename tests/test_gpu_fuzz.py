@@ -24,7 +24,14 @@ def _shapes(n, seed):
     return out
 
 
-@pytest.mark.parametrize("H,W,D", _shapes(40, seed=2026))
+def _long_path_shapes():
+    """Paths of several 16/32-pixel segments in every family, at every lanes-per-value count."""
+    rng = np.random.default_rng(5)
+    return [(int(rng.integers(40, 130)), int(rng.integers(40, 160)), D)
+            for D in (32, 64, 128, 192, 256, 512) for _ in range(2)]
+
+
+@pytest.mark.parametrize("H,W,D", _shapes(120, seed=2026) + _long_path_shapes())
 def test_fuzz_all_ops(device, oracle, H, W, D):
     import stereomatch
     rng = np.random.default_rng(H * 131 + W * 17 + D)
