@@ -678,8 +678,10 @@ __global__ __launch_bounds__(kSgmBlock) void sgm_pair_kernel(const float *__rest
 #pragma unroll
           for (int e = 0; e < VPL; ++e)
             if ((VEC || d0 + e < D) && o.v[e] < best) { best = o.v[e]; idx = d0 + e; }
+          // Lanes hold increasing disparities, so the first lane whose value equals the wave
+          // minimum holds the lowest winning index (best is never NaN: it starts at +inf).
           const float m = wave_min_f32(best);
-          const int win = wave_min_i32(best == m ? idx : 0x7fffffff);
+          const int win = __builtin_amdgcn_readlane(idx, __builtin_ctzll(__ballot(best == m)));
           const float first = read_lane(o.v[0], 0);
           if (lane == 0) disp_all[(size_t)b * npix + (size_t)q] = (first != first) ? 0 : win;
         }
