@@ -46,9 +46,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 WORKLOADS = {
     # name: (H, W, D, default pairs per GPU per step, digest of pair 0's disparity map)
     # digests: SURVEY.md Appendix C, SSD+SGM+WTA on the seed-0 pair (reference CPU output).
-    "teddy": dict(H=375, W=450, D=128, batch=64, digest="9693be8fb6aa9b99",
+    "teddy": dict(H=375, W=450, D=128, batch=256, digest="9693be8fb6aa9b99",
                   config="Teddy 450x375, SSD + 8-path SGM + WTA, D=128"),
-    "1080p": dict(H=1080, W=1920, D=256, batch=4, digest=None,
+    "1080p": dict(H=1080, W=1920, D=256, batch=8, digest=None,
                   config="1920x1080 synthetic pair, SSD + SGM + WTA, D=256"),
 }
 
