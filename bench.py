@@ -355,9 +355,10 @@ def main():
         out["cpu_baseline"] = cpu_baseline()
     elif rank == 0:
         out["cpu_baseline"] = None
+    import torch.distributed as dist
     if world > 1:
-        import torch.distributed as dist
         dist.barrier()
+    if dist.is_available() and dist.is_initialized():  # also the 1-rank RCCL rehearsal group
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
