@@ -48,7 +48,9 @@ WORKLOADS = {
     # digests: SURVEY.md Appendix C, SSD+SGM+WTA on the seed-0 pair (reference CPU output).
     "teddy": dict(H=375, W=450, D=128, batch=256, digest="9693be8fb6aa9b99",
                   config="Teddy 450x375, SSD + 8-path SGM + WTA, D=128"),
-    "1080p": dict(H=1080, W=1920, D=256, batch=8, digest=None,
+    # digest: the oracle's (tests/golden/oracle_digests.json; the survey did not run the
+    # reference at this size).  batch 8 = config 5's per-GPU share (64 pairs over 8 GPUs).
+    "1080p": dict(H=1080, W=1920, D=256, batch=8, digest="63d42685337550c1",
                   config="1920x1080 synthetic pair, SSD + SGM + WTA, D=256"),
 }
 
@@ -174,10 +176,11 @@ def timed_run(job, steps, warmup, world):
     return elapsed, stage_ms
 
 
-def roofline(job, sgm_ms, traffic=None):
+def roofline(job, sgm_ms, traffic_and_note=(None, None)):
+    traffic, note = traffic_and_note
     algorithmic = 8.0 * job.n_elems * job.batch  # read cost once + write sum once
     achieved = algorithmic / (sgm_ms * 1e-3) / 1e9
-    return {"bound": "hbm",
+    return {"bound": "hbm", "traffic_note": note,
             "kernel": "semiglobal aggregation with fused WTA: sgm_ckpt_kernel + 4 x sgm_pair_kernel "
                       "(stm_sgm_wta_f32)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -187,16 +190,37 @@ def roofline(job, sgm_ms, traffic=None):
             "traffic_rate": None if traffic is None else round(traffic / (sgm_ms * 1e-3) / 1e9, 1)}
 
 
+def csrc_sha16():
+    """Hash of the kernel sources the loaded library was built from (they travel with it)."""
+    import hashlib
+    d = os.path.join(ROOT, "stereo-matching_amd", "csrc")
+    h = hashlib.sha256()
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h")) or fn == "Makefile":
+            with open(os.path.join(d, fn), "rb") as f:
+                h.update(fn.encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()[:16]
+
+
 def load_traffic(name, batch):
     """HBM bytes the aggregation stage moves per step: the per-pair figure of the committed
-    PMC summary (profiles/traffic.json) times the pairs per step; None without a summary."""
+    PMC summary (profiles/traffic.json) times the pairs per step.  The summary is stamped
+    with the hash of the kernel sources it was measured on (profiles/summarize.py); when
+    that differs from the sources in this tree the figure is stale and None is returned
+    (with the reason), so an old PMC number cannot ride on new kernels."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            per_pair = json.load(f).get(name + "_per_pair")
-        return None if per_pair is None else int(per_pair) * batch
+            doc = json.load(f)
     except (OSError, ValueError):
-        return None
+        return None, "no profiles/traffic.json"
+    per_pair = doc.get(name + "_per_pair")
+    if per_pair is None:
+        return None, "profiles/traffic.json has no %s_per_pair" % name
+    have, want = doc.get("csrc_sha16"), csrc_sha16()
+    if have != want:
+        return None, "profiles/traffic.json was measured on kernel sources %s, this tree is %s" % (have, want)
+    return int(per_pair) * batch, None
 
 
 def cpu_baseline(budget_s=20.0):
@@ -230,6 +254,41 @@ def cpu_baseline(budget_s=20.0):
                       "host cores; per pair: SSD %.2f s, SGM %.2f s, WTA %.3f s"
                       % (done, os.cpu_count() or 0, stages[0] / done, stages[1] / done,
                          stages[2] / done)}
+
+
+def latency_b1(device, reps=20):
+    """The reference's call shape: ONE pair per Pipeline.estimate call (pipeline.py:69-94 has
+    no batch axis).  Milliseconds per call, HIP events around `reps` back-to-back calls after
+    two warm-up calls; inputs resident.  `unit_images_ordered` is the same Teddy pipeline on
+    /255-scaled images (the reference's own fixtures, tests/conftest.py:24-29), which take the
+    ORDERED SSD path: exact for any input and ~10x the integer-image fill."""
+    import stereomatch
+    out = {}
+    for key, (H, W, D, scale) in {"teddy": (375, 450, 128, 1.0), "1080p": (1080, 1920, 256, 1.0),
+                                  "teddy_unit_images_ordered": (375, 450, 128, 1.0 / 255.0)}.items():
+        L, R = synthetic_pair(H, W, seed=0)
+        Lg = torch.from_numpy(L * np.float32(scale)).to(device)
+        Rg = torch.from_numpy(R * np.float32(scale)).to(device)
+        cost = _TimedCost(stereomatch.cost.SSD(D, kernel_size=7))
+        pipe = stereomatch.Pipeline(cost, stereomatch.disparity_reduce.WinnerTakesAll(),
+                                    stereomatch.aggregation.Semiglobal(0.1, 0.2))
+        for _ in range(2):
+            pipe.estimate(Lg, Rg)
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(reps)]
+        torch.cuda.synchronize()
+        for k in range(reps):
+            ev[k][0].record()
+            cost.event = ev[k][1]
+            pipe.estimate(Lg, Rg)
+            ev[k][2].record()
+        torch.cuda.synchronize()
+        ssd = float(np.median([e[0].elapsed_time(e[1]) for e in ev]))
+        agg = float(np.median([e[1].elapsed_time(e[2]) for e in ev]))
+        out[key] = {"ms_per_call": round(ssd + agg, 4), "ssd_ms": round(ssd, 4),
+                    "sgm_wta_ms": round(agg, 4), "pairs_per_s": round(1e3 / (ssd + agg), 1)}
+        del pipe, cost
+        torch.cuda.empty_cache()
+    return out
 
 
 def config3_line(device, steps, batch=16):
@@ -269,6 +328,7 @@ def main():
     ap.add_argument("--also-batch", type=int, default=0, help="pairs per step of the second workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config3", action="store_true", help="skip the Birchfield+SGM+DP extra line")
+    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 per-call latencies")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--rehearse-nccl", action="store_true",
                     help="rehearsal only: 1-rank RCCL group, gather code path exercised")
@@ -302,15 +362,35 @@ def main():
     from stereomatch import _native
     _native.lib()  # no HIP library -> fail loudly, there is no fallback
 
+    def gate(job, label):
+        """Parity gate before any timing: rank 0's pair 0 (seed 0) must reproduce the pinned
+        disparity map.  The verdict is shared, so that every rank stops together instead of
+        the others waiting in a collective for a rank that has raised."""
+        disp = job.step(world=1)
+        torch.cuda.synchronize()
+        ok, got = 1, None
+        if rank == 0 and job.w["digest"]:
+            got = digest16(disp[0].cpu().numpy())
+            ok = int(got == job.w["digest"])
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([ok], dtype=torch.int32,
+                             device=device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = int(t.item())
+        if not ok:
+            if rank == 0:
+                print("parity gate failed (%s): %s != %s" % (label, got, job.w["digest"]),
+                      file=sys.stderr, flush=True)
+            if world > 1:
+                import torch.distributed as dist
+                dist.destroy_process_group()
+            sys.exit(1)
+
     name = args.workload
     batch = args.batch or WORKLOADS[name]["batch"]
     job = Job(name, batch, rank, device)
-    # Parity gate before any timing: pair 0 must reproduce the reference's disparity map.
-    disp = job.step(world=1)
-    torch.cuda.synchronize()
-    if rank == 0 and WORKLOADS[name]["digest"]:
-        got = digest16(disp[0].cpu().numpy())
-        assert got == WORKLOADS[name]["digest"], "parity gate failed: %s" % got
+    gate(job, name)
     elapsed, stage_ms = timed_run(job, args.steps, args.warmup, world)
     pairs = batch * world * args.steps
     value = pairs / elapsed
@@ -326,27 +406,36 @@ def main():
         "stage_ms": {"ssd": round(stage_ms[0], 4), "sgm_wta_fused": round(stage_ms[1], 4),
                      "sgm_alone_unfused": round(job.unfused_sgm_ms(), 4)},
         "roofline": roofline(job, stage_ms[1], load_traffic(name, batch)),
+        "csrc_sha16": csrc_sha16(),
     }
     del job
     torch.cuda.empty_cache()
 
-    if args.also and args.also != name and world == 1:
+    if args.also and args.also != name:
+        # Second workload, on every rank count: at N = 8 the 1080p leg with 8 pairs per GPU
+        # is BASELINE config 5 (64 pairs sharded over 8 GPUs, disparity maps gathered).
         w2 = WORKLOADS[args.also]
         b2 = args.also_batch or w2["batch"]
         job2 = Job(args.also, b2, rank, device)
-        e2, s2 = timed_run(job2, args.also_steps, 1, 1)
+        gate(job2, args.also)
+        e2, s2 = timed_run(job2, args.also_steps, 1, world)
         d7 = float((job2.disp == 7).float().mean())
         out["also"] = {
-            "workload": w2["config"], "value": round(b2 * args.also_steps / e2, 3),
-            "unit": "pairs/s", "pairs_per_step": b2, "steps": args.also_steps,
+            "workload": w2["config"] + (" x %d pairs sharded over %d GPUs" % (b2 * world, world)
+                                        if world > 1 else ""),
+            "value": round(b2 * world * args.also_steps / e2, 3),
+            "unit": "pairs/s", "n_gpus": world, "pairs_per_gpu_per_step": b2, "steps": args.also_steps,
             "ms_per_step": round(e2 / args.also_steps * 1e3, 3),
             "stage_ms": {"ssd": round(s2[0], 4), "sgm_wta_fused": round(s2[1], 4),
                          "sgm_alone_unfused": round(job2.unfused_sgm_ms(), 4)},
             "roofline": roofline(job2, s2[1], load_traffic(args.also, b2)),
-            "pixels_at_true_disparity": round(d7, 4),
+            "pixels_at_true_disparity": round(d7, 4), "parity_gate": w2["digest"],
         }
         del job2
         torch.cuda.empty_cache()
+
+    if world == 1 and not args.no_latency:
+        out["latency_b1"] = latency_b1(device)
 
     if world == 1 and not args.no_config3:
         out["also_config3"] = config3_line(device, args.also_steps)

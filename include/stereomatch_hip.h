@@ -128,6 +128,17 @@ int stm_birchfield_ex_f32(const float *left, const float *right, float *cost,
  *                       re-walk a corner diagonal and skip others). */
 #define STM_SGM_FULL_MIN 8
 #define STM_SGM_TRUE_PATHS 16
+/* Non-finite inputs.  The aggregation's minima are v_min_f32 instructions, which ignore a NaN
+ * operand; the reference's are strict-'<' scans (src/semiglobal.cpp:11-16,130), which keep a
+ * NaN FIRST operand.  The two agree on every volume whose pixels all have a finite cost at
+ * some d < D-1 (every volume stm_ssd_f32 / stm_birchfield_f32 produce: d = 0 is finite): no
+ * NaN ever arises.  A pixel that is +inf at every d < D-1 makes the recurrence compute
+ * (C + inf) - inf; from there on NaN and -inf spread along every path through it, and by
+ * default WHICH of NaN / +-inf / a finite value lands on which element of those pixels'
+ * sums is unspecified (pixels that no path reaches after such a pixel are unaffected).
+ *   STM_SGM_EXACT_NONFINITE  reproduce the reference's placement of NaN and +-inf as well
+ *                       (two more selects per element and step: 1-3 % slower). */
+#define STM_SGM_EXACT_NONFINITE 32
 size_t stm_sgm_workspace_bytes(int H, int W, int D, int batch, int flags);
 int stm_sgm_f32(const float *cost, const float *left, float *out, int H, int W,
                 int D, float penalty1, float penalty2, int flags,

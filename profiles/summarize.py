@@ -19,6 +19,20 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def csrc_sha16():
+    """Hash of the kernel sources (same function as bench.py's): stamped into traffic.json so
+    that bench.py can tell a PMC figure measured on other kernels from a current one.  Run
+    this script on the tree the profile was taken on."""
+    import hashlib
+    d = os.path.join(os.path.dirname(HERE), "stereo-matching_amd", "csrc")
+    h = hashlib.sha256()
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h")) or fn == "Makefile":
+            with open(os.path.join(d, fn), "rb") as f:
+                h.update(fn.encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()[:16]
+
+
 def short(name):
     name = name.replace("void stm::(anonymous namespace)::", "").replace("stm::(anonymous namespace)::", "")
     return name.split("(")[0]
@@ -104,6 +118,7 @@ def main():
                         "multiplies by its pairs per step), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; "
                         "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128 B request); "
                         "tag " + tag)
+    traffic["csrc_sha16"] = csrc_sha16()
     with open(os.path.join(HERE, "traffic.json"), "w") as f:
         json.dump(traffic, f, indent=1)
     print(json.dumps(traffic, indent=1))

@@ -145,6 +145,17 @@ __device__ __forceinline__ int group_min_i32(int v) {
   return v;
 }
 
+// Hand-off point of data that lanes of ONE wave pass to each other through LDS: everything the
+// wave stored to LDS before this point is ordered before every LDS load after it (and loads
+// before it stay before later stores).  LDS executes a wave's accesses in program order, so
+// no instruction is needed; the wavefront-scope release/acquire pair plus the scheduling
+// barrier stop the compiler from moving a may-not-alias load above the store it depends on.
+__device__ __forceinline__ void wave_lds_handoff() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ int wave_uniform(int v) {
   return __builtin_amdgcn_readfirstlane(v);
 }

@@ -269,6 +269,7 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
   float4 regs[LP];
   fetch(regs);
   park(0, regs);
+  wave_lds_handoff();  // init[] and tile[0] are read by other lanes below
   float hist[O];
 #pragma unroll
   for (int j = 0; j < O; ++j) hist[j] = inf;
@@ -347,6 +348,7 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
       unsigned *mine = &pbuf[lane * PB + (q & 15) * LP];
 #pragma unroll
       for (int u = 0; u < LP; ++u) mine[u] = pk[u];
+      wave_lds_handoff();  // the finishing columns' records are read by other lanes
       const int vd = (blk + 1) & 15;           // lanes finishing a column in this block
       const int qd = blk - vd;                 // = 15 (mod 16)
       const int cd = vd + 16 * (qd >> 4);      // that column (negative before the first one)
@@ -368,8 +370,9 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
       }
     }
     park(cur ^ 1, regs);
+    wave_lds_handoff();  // tile[cur ^ 1] (and pbuf) change hands between iterations
   }
-  // Flush the final costs.
+  // Flush the final costs (fin[] was written by the lanes that own the last column).
   float *rowfin = rowfin_all + ((size_t)b * H + (rowok ? row : 0)) * D;
   if (rowok)
     for (int d = v; d < D; d += 16) rowfin[d] = fin[rq][d];

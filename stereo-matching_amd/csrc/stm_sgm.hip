@@ -38,8 +38,21 @@
 
 #include "stm_common.h"
 
+// This file is compiled twice (csrc/Makefile): as stm_sgm.o with STM_SGM_EXACT = 0, which holds
+// the C entry points, and as stm_sgm_exact.o with STM_SGM_EXACT = 1, which holds the same
+// kernels with the reference's treatment of NaN operands (STM_SGM_EXACT_NONFINITE, see
+// sgm_step) behind stm::sgm_run_exact().
+#ifndef STM_SGM_EXACT
+#define STM_SGM_EXACT 0
+#endif
+
 namespace stm {
+int sgm_run_exact(const float *cost, const float *left, float *out, int32_t *disp, int H, int W,
+                  int D, float penalty1, float penalty2, int flags, void *workspace,
+                  size_t workspace_bytes, int batch, void *stream, int final_mode);
 namespace {
+
+constexpr bool kExactNonFinite = STM_SGM_EXACT != 0;
 
 constexpr int kSgmBlock = 256;
 constexpr int kPF = 4;  // pixels kept in flight per wave
@@ -211,6 +224,13 @@ __device__ __forceinline__ Row<VPL> sgm_step(const Row<VPL> &prev, const Row<VPL
   if constexpr (!VEC) {
     if (X.dlim == 0) m = read_lane(prev.v[0], 0);  // D = 1: empty range, *end() is element D-1
   }
+  if constexpr (kExactNonFinite) {
+    // std::min_element (cpp:130) is a strict-'<' scan that starts at element 0: a NaN there
+    // is never replaced, a NaN further on never wins.  v_min_f32 ignores NaN operands, which
+    // is the second half of that rule; the first half is this select.
+    const float head = read_lane(prev.v[0], 0);
+    m = (head != head) ? head : m;
+  }
   const float far = m + p2a;
   lane_up_add(X.below, prev.v[VPL - 1], X.p1v);  // L(d0-1) + P1
   lane_down_add(X.above, prev.v[0], X.p1v);      // L(d0+VPL) + P1
@@ -224,7 +244,9 @@ __device__ __forceinline__ Row<VPL> sgm_step(const Row<VPL> &prev, const Row<VPL
     const float hi = j == VPL - 1 ? X.above : w[j + 1];
     // get_min (cpp:11-16) is a strict-'<' chain; as a value that is the minimum of the
     // four candidates (v_min3_f32 + v_min_f32).
-    const float t = vmin_f32(vmin3_f32(prev.v[j], lo, hi), far);
+    float t = vmin_f32(vmin3_f32(prev.v[j], lo, hi), far);
+    // get_min starts from L(d) and replaces it by a smaller candidate: a NaN L(d) stays.
+    if constexpr (kExactNonFinite) t = (prev.v[j] != prev.v[j]) ? prev.v[j] : t;
     const float a = c.v[j] + t;
     cur.v[j] = a - m;
   }
@@ -808,10 +830,12 @@ static SgmPlan sgm_plan(int H, int W, int D, int batch, bool paired, bool true_p
   return plan;
 }
 
+#if !STM_SGM_EXACT
 extern "C" size_t stm_sgm_workspace_bytes(int H, int W, int D, int batch, int flags) {
   if (H <= 0 || W <= 0 || D <= 0 || batch <= 0 || D > STM_MAX_DISPARITY) return 0;
   return sgm_plan(H, W, D, batch, !(flags & STM_SGM_SINGLE_PASSES), (flags & STM_SGM_TRUE_PATHS) != 0).total_floats * sizeof(float);
 }
+#endif
 
 namespace stm {
 namespace {
@@ -861,6 +885,11 @@ static int sgm_run(const float *cost, const float *left, float *out, int32_t *di
                    int D, float penalty1, float penalty2, int flags, void *workspace,
                    size_t workspace_bytes, int batch, void *stream, int final_mode) {
   using namespace stm;
+#if !STM_SGM_EXACT
+  if (flags & STM_SGM_EXACT_NONFINITE)
+    return sgm_run_exact(cost, left, out, disp, H, W, D, penalty1, penalty2, flags, workspace,
+                         workspace_bytes, batch, stream, final_mode);
+#endif
   STM_REQUIRE(cost && left && out, STM_EINVAL, "stm_sgm_f32: null pointer");
   STM_REQUIRE(H > 0 && W > 0 && D > 0 && batch > 0, STM_EINVAL,
               "stm_sgm_f32: non-positive size (H=%d W=%d D=%d batch=%d)", H, W, D, batch);
@@ -966,6 +995,14 @@ static int sgm_run(const float *cost, const float *left, float *out, int32_t *di
   return STM_OK;
 }
 
+#if STM_SGM_EXACT
+int stm::sgm_run_exact(const float *cost, const float *left, float *out, int32_t *disp, int H,
+                       int W, int D, float penalty1, float penalty2, int flags, void *workspace,
+                       size_t workspace_bytes, int batch, void *stream, int final_mode) {
+  return sgm_run(cost, left, out, disp, H, W, D, penalty1, penalty2, flags, workspace,
+                 workspace_bytes, batch, stream, final_mode);
+}
+#else
 extern "C" int stm_sgm_f32(const float *cost, const float *left, float *out, int H, int W,
                            int D, float penalty1, float penalty2, int flags, void *workspace,
                            size_t workspace_bytes, int batch, void *stream) {
@@ -983,3 +1020,4 @@ extern "C" int stm_sgm_wta_f32(const float *cost, const float *left, float *sum,
   return sgm_run(cost, left, sum, disparity, H, W, D, penalty1, penalty2, flags, workspace,
                  workspace_bytes, batch, stream, (flags & STM_SGM_KEEP_SUM) ? 1 : 2);
 }
+#endif  // !STM_SGM_EXACT

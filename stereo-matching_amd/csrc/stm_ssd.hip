@@ -455,8 +455,10 @@ __device__ __forceinline__ void slide_band(const float *__restrict__ L, const fl
   SlideRow e = slide_fetch(L, R, r + kSlideK - 1, live_enter(r), W, c0, d0, lane);
   SlideRow x = slide_fetch(L, R, r - kSlideK - 1, live_leave(r), W, c0, d0, lane);
   for (; r < r_end; ++r) {
+    wave_lds_handoff();  // the previous row's staged samples have been read by every lane
     slide_stage(lds_e, e, lane);
     slide_stage(lds_x, x, lane);
+    wave_lds_handoff();  // lane l reads what lanes l-63..l+76 staged
     const SlideRow ce = e, cx = x;
     // Next iteration's rows are in flight while this one computes.
     e = slide_fetch(L, R, r + kSlideK, live_enter(r + 1) && r + 1 < r_end, W, c0, d0, lane);

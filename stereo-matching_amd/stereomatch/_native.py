@@ -20,6 +20,7 @@ STM_SGM_SINGLE_PASSES = 2
 STM_SGM_KEEP_SUM = 4
 STM_SGM_FULL_MIN = 8
 STM_SGM_TRUE_PATHS = 16
+STM_SGM_EXACT_NONFINITE = 32
 STM_DP_MODES = {"reference": 0, "corrected": 1}
 STM_BT_INDEXING = {"reference": 0, "padded": 1}
 
@@ -81,6 +82,17 @@ def require_gpu(reference: torch.Tensor, *others: torch.Tensor) -> None:
         if t.device != reference.device:
             raise RuntimeError("Check failed: Expected a %s tensor"
                                % ("gpu" if reference.is_cuda else "cpu"))
+
+
+def require_float32(volume: torch.Tensor, op: str, reference_dispatch: str) -> None:
+    """The device path computes in float32 only.  The reference additionally dispatches
+    float64 (``AT_DISPATCH_FLOATING_TYPES``) for this op; that is declined here with a message
+    that says so -- never served by a CPU or reduced-precision fallback."""
+    if volume.dtype != torch.float32:
+        raise RuntimeError(
+            "%s: %s tensors are not supported on the MI355X path, which implements float32 only "
+            "(the reference also dispatches float64 here: %s); convert with .float()"
+            % (op, str(volume.dtype).replace("torch.", ""), reference_dispatch))
 
 
 def stream_ptr(device: torch.device) -> int:

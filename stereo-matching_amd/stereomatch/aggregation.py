@@ -16,13 +16,21 @@ class Semiglobal:
     eight path directions summed in its path-table order, including its quirks for the
     inverse diagonals and the minimum over ``d < D-1``.
 
+    Non-finite inputs: that holds for every volume whose pixels all have a finite cost at
+    some ``d < D-1`` (all volumes ``SSD`` and ``Birchfield`` produce).  A pixel that is +inf
+    at every ``d < D-1`` makes the recurrence compute ``(C + inf) - inf``; NaN and -inf then
+    spread along every path through it, and with ``exact_nonfinite=False`` (default) which of
+    them lands on which element is unspecified.  ``exact_nonfinite=True``
+    (``STM_SGM_EXACT_NONFINITE``) reproduces the reference's placement too, 1-3 % slower.
+
     The reference zero-fills the output and accumulates into it
     (``aggregation.py:51``); here the first pass overwrites the output instead, which
     gives the same values without the extra fill and read.
     """
 
     def __init__(self, penalty1: float = 0.1, penalty2: float = 0.2, single_passes: bool = False,
-                 paths: str = "reference", full_min: bool = False):
+                 paths: str = "reference", full_min: bool = False,
+                 exact_nonfinite: bool = False):
         if paths not in ("reference", "hirschmuller"):
             raise ValueError("Semiglobal paths must be 'reference' or 'hirschmuller'")
         self.penalty1 = penalty1
@@ -33,6 +41,7 @@ class Semiglobal:
         # full_min=True: the per-step minimum covers all D disparities (Q5).
         self.paths = paths
         self.full_min = full_min
+        self.exact_nonfinite = exact_nonfinite
         # False (default): a direction and its inverse share one pass over the sum (less HBM
         # traffic, larger workspace); True: eight separate passes.  Same bits either way.
         self.single_passes = single_passes
@@ -60,8 +69,7 @@ class Semiglobal:
 
     def _run(self, cost_volume, left_image, sga_volume, disparity_img, fused, keep_sum=False):
         _native.require_gpu(cost_volume, left_image)
-        if cost_volume.dtype != torch.float32:
-            raise RuntimeError("SemiglobalCPU: float32 cost volumes only on this device path")
+        _native.require_float32(cost_volume, "RunSemiglobal", "src/semiglobal.cpp:182")
         batch, (height, width, max_disparity) = _native.split_batch(cost_volume, 3)
         if tuple(left_image.shape) != tuple(cost_volume.shape[:-1]):
             raise RuntimeError("stereomatch: left image shape %s does not match cost volume %s"
@@ -78,6 +86,8 @@ class Semiglobal:
             flags |= _native.STM_SGM_TRUE_PATHS
         if self.full_min:
             flags |= _native.STM_SGM_FULL_MIN
+        if self.exact_nonfinite:
+            flags |= _native.STM_SGM_EXACT_NONFINITE
         if fused:
             disparity_img = output_tensor(cost_volume.shape[:-1], torch.int32, device,
                                           reuse=disparity_img)

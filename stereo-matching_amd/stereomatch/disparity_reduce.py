@@ -32,8 +32,7 @@ class WinnerTakesAll:
         if self.require_power_of_two and not is_power_of_two(max_disparity):
             raise RuntimeError("Winner takes all requires max disparity "
                                "(`cost_volume.size(-1)`) to be a power of 2.")
-        if cost_volume.dtype != torch.float32:
-            raise RuntimeError("RunWinnersTakeAll: float32 cost volumes only on this device path")
+        _native.require_float32(cost_volume, "RunWinnersTakeAll", "src/winners_take_all.cu:99,108")
         volume = cost_volume.contiguous()
         with torch.cuda.device(device):
             _native.check(_native.lib().stm_wta_f32(
@@ -65,8 +64,8 @@ class DynamicProgramming:
                  disparity_img: Optional[torch.Tensor] = None) -> torch.Tensor:
         _native.require_gpu(cost_volume)
         batch, (height, width, max_disparity) = _native.split_batch(cost_volume, 3)
-        if cost_volume.dtype != torch.float32:
-            raise RuntimeError("DynamicProgramming: float32 cost volumes only on this device path")
+        _native.require_float32(cost_volume, "RunDynamicProgramming",
+                                "src/dynamic_programming.cu:199,213")
         device = cost_volume.device
         disparity_img = output_tensor(cost_volume.shape[:-1], torch.int32, device,
                                       reuse=disparity_img)

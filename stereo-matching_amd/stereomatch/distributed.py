@@ -73,5 +73,10 @@ def estimate_sharded(pipeline, lefts: torch.Tensor, rights: torch.Tensor, group=
     else:
         rank, world = 0, 1
     a, b = pair_shard(n, rank, world)
-    local = pipeline.estimate(lefts[a:b], rights[a:b])
+    if b > a:
+        local = pipeline.estimate(lefts[a:b], rights[a:b])
+    else:
+        # Fewer pairs than ranks: this rank owns none.  It still takes part in the gather
+        # (with a zero-length block), otherwise the other ranks would wait for it for ever.
+        local = torch.empty((0,) + tuple(lefts.shape[1:]), dtype=torch.int32, device=lefts.device)
     return gather_disparities(local, n_pairs=n, group=group)

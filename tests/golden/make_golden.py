@@ -53,9 +53,33 @@ def write_case(name, H, W, D, k, seed, with_reference_dp):
     print("wrote", name, {k: getattr(v, "shape", v) for k, v in out.items()})
 
 
+def write_oracle_digests():
+    """Digests of the ORACLE's outputs (not of the reference's: the survey session did not
+    run the reference at this size) for configs 4/5: the 1080p x 256 seed-0 pair through
+    SSD(256, k=7) -> SGM(0.1, 0.2) -> WTA.  The oracle itself is pinned by check_digests().
+    Takes ~1.5 minutes on one core."""
+    H, W, D = 1080, 1920, 256
+    L, R = oracle.synthetic_pair(H, W, seed=0)
+    C = oracle.ssd(L, R, D, 7)
+    S = oracle.sgm(C, L)
+    disp = oracle.wta(S)
+    out = {"_source": "oracle/stm_oracle.c outputs (sha256, first 16 hex, raw little-endian bytes) "
+                      "on the SURVEY 8(d) generator, seed 0; written by tests/golden/make_golden.py",
+           "1080p 1080x1920x256": dict(H=H, W=W, D=D, L=oracle.digest16(L), R=oracle.digest16(R),
+                                       ssd=oracle.digest16(C), ssd_wta=oracle.digest16(oracle.wta(C)),
+                                       sgm=oracle.digest16(S), ssd_sgm_wta=oracle.digest16(disp),
+                                       pixels_at_true_disparity=float((disp == 7).mean()))}
+    with open(os.path.join(HERE, "oracle_digests.json"), "w") as f:
+        json.dump(out, f, indent=1)
+        f.write("\n")
+    print("wrote oracle_digests.json", out)
+
+
 if __name__ == "__main__":
     oracle.build()
     check_digests()
+    if "--with-1080p" in sys.argv:
+        write_oracle_digests()
     write_case("tiny_wide", 24, 40, 16, 7, 0, True)    # W > H: re-walked diagonals (Q6)
     write_case("tiny_tall", 40, 24, 16, 7, 0, False)   # H > W+1: pre-walks; DP reference mode n/a
     write_case("dp_square", 20, 20, 16, 3, 1, True)    # D <= H <= W

@@ -51,7 +51,7 @@ def _worker(rank, world, port, n_pairs, H, W, D, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_pairs", [4, 5])
+@pytest.mark.parametrize("n_pairs", [4, 5, 1])  # 1: fewer pairs than ranks (empty shard)
 def test_two_ranks_shard_and_gather(tmp_path, oracle, n_pairs):
     H, W, D, world = 12, 20, 8, 2
     mp.spawn(_worker, args=(world, _free_port(), n_pairs, H, W, D, str(tmp_path)), nprocs=world,

@@ -149,3 +149,46 @@ def test_teddy_batch_takes_the_streaming_variants_and_matches_single_pairs(devic
         S1 = sgm(C1, Lb[b])
         assert torch.equal(S1.view(torch.int32), Sb[b].view(torch.int32)), "sgm pair %d" % b
         assert torch.equal(wta(S1), fused_b[b]), "fused pair %d" % b
+
+
+with open(os.path.join(HERE, "golden", "oracle_digests.json")) as f:
+    ORACLE_GOLDEN = json.load(f)
+
+
+def test_config5_share_eight_1080p_pairs(device, oracle):
+    """Config 5's per-GPU share: a batch of eight 1080p x 256 pairs through SSD -> SGM -> WTA
+    (fused and unfused).  Pair 0 must hash to the oracle digests committed in
+    tests/golden/oracle_digests.json (cost volume, aggregated volume, disparity map) and
+    every pair must equal its own single-pair run bit for bit."""
+    import stereomatch
+    g = ORACLE_GOLDEN["1080p 1080x1920x256"]
+    H, W, D, B = g["H"], g["W"], g["D"], 8
+    pairs = [oracle.synthetic_pair(H, W, seed=s) for s in range(B)]
+    assert digest16(pairs[0][0]) == g["L"] and digest16(pairs[0][1]) == g["R"]
+    Lb = torch.from_numpy(np.stack([p[0] for p in pairs])).to(device)
+    Rb = torch.from_numpy(np.stack([p[1] for p in pairs])).to(device)
+    ssd = stereomatch.cost.SSD(D)
+    sgm = stereomatch.aggregation.Semiglobal()
+    wta = stereomatch.disparity_reduce.WinnerTakesAll()
+    pipe = stereomatch.Pipeline(stereomatch.cost.SSD(D), stereomatch.disparity_reduce.WinnerTakesAll(),
+                                stereomatch.aggregation.Semiglobal())
+    fused_b = pipe.estimate(Lb, Rb).clone()
+    del pipe
+    torch.cuda.empty_cache()
+    Cb = ssd(Lb, Rb)
+    Sb = sgm(Cb, Lb)
+    disp_b = wta(Sb)
+    assert torch.equal(disp_b, fused_b)
+    assert digest16(Cb[0]) == g["ssd"], "cost volume of pair 0"
+    assert digest16(Sb[0]) == g["sgm"], "aggregated volume of pair 0"
+    assert digest16(fused_b[0]) == g["ssd_sgm_wta"], "disparity map of pair 0"
+    assert abs(float((fused_b[0] == 7).float().mean()) - g["pixels_at_true_disparity"]) < 1e-6
+    ssd1 = stereomatch.cost.SSD(D)
+    sgm1 = stereomatch.aggregation.Semiglobal()
+    C1 = S1 = None
+    for b in range(B):
+        C1 = ssd1(Lb[b], Rb[b], cost_volume=C1)
+        assert torch.equal(C1.view(torch.int32), Cb[b].view(torch.int32)), "ssd pair %d" % b
+        S1 = sgm1(C1, Lb[b], S1)
+        assert torch.equal(S1.view(torch.int32), Sb[b].view(torch.int32)), "sgm pair %d" % b
+        assert torch.equal(wta(S1), fused_b[b]), "disparity pair %d" % b

@@ -181,6 +181,53 @@ def test_sgm_on_random_volume_matches_oracle(device, oracle, H, W, D, kind):
     assert_same_bits(got.cpu().numpy(), want, "sgm " + kind)
 
 
+@pytest.mark.parametrize("H,W,D", [(24, 40, 16), (40, 24, 16), (20, 22, 64), (13, 30, 128),
+                                    (9, 21, 256), (10, 14, 100), (7, 9, 2), (33, 34, 512),
+                                    (70, 200, 64), (50, 35, 256)])
+@pytest.mark.parametrize("single", [False, True])
+def test_sgm_exact_nonfinite_on_inf_volumes(device, oracle, H, W, D, single):
+    """STM_SGM_EXACT_NONFINITE: volumes with 30 % +inf entries and all-+inf pixels, NOT patched
+    to keep d = 0 finite.  The recurrence then makes (C + inf) - inf; the reference's
+    strict-'<' minima (src/semiglobal.cpp:11-16,130) decide where NaN, -inf and +inf land,
+    and the flag reproduces that placement (a NaN equals any NaN; everything else bit for
+    bit), in the sum and in the fused reduction."""
+    import stereomatch
+    rng = np.random.default_rng(31 * H + W + D)
+    C = _random_volume(rng, H, W, D, "inf")
+    for _ in range(4):  # a few more pixels without any finite cost, away from the corner
+        C[int(rng.integers(0, H)), int(rng.integers(0, W)), :] = np.inf
+    image = rng.integers(0, 5, size=(H, W)).astype(np.float32)
+    want = oracle.sgm(C, image, 0.5, 3.0)
+    assert np.isnan(want).any(), "the case is meant to produce NaNs"
+    sgm = stereomatch.aggregation.Semiglobal(0.5, 3.0, single_passes=single, exact_nonfinite=True)
+    got = sgm(_gpu(C, device), _gpu(image, device))
+    assert_same_bits(got.cpu().numpy(), want, "sgm exact non-finite")
+    if not single:
+        _, disp = sgm.aggregate_and_reduce(_gpu(C, device), _gpu(image, device))
+        assert_same_bits(disp.cpu().numpy(), oracle.wta(want), "fused wta on NaN-bearing sums")
+
+
+def test_sgm_default_nonfinite_contract(device, oracle):
+    """The documented default (include/stereomatch_hip.h, STM_SGM_EXACT_NONFINITE): with an
+    all-+inf pixel only the pixels a path reaches AFTER it may differ from the reference; all
+    other pixels' sums are the reference's bit for bit."""
+    import stereomatch
+    H, W, D = 21, 33, 64
+    rng = np.random.default_rng(7)
+    C = _random_volume(rng, H, W, D, "float")
+    py, px = 9, 14
+    C[py, px, :] = np.inf
+    image = rng.integers(0, 5, size=(H, W)).astype(np.float32)
+    want = oracle.sgm(C, image, 0.5, 3.0)
+    got = stereomatch.aggregation.Semiglobal(0.5, 3.0)(_gpu(C, device), _gpu(image, device)).cpu().numpy()
+    yy, xx = np.mgrid[0:H, 0:W]
+    on_a_line = (yy == py) | (xx == px) | (yy - py == xx - px) | (yy - py == px - xx)
+    assert_same_bits(got[~on_a_line], want[~on_a_line], "pixels off the eight lines")
+    exact = stereomatch.aggregation.Semiglobal(0.5, 3.0, exact_nonfinite=True)(
+        _gpu(C, device), _gpu(image, device)).cpu().numpy()
+    assert_same_bits(exact, want, "exact flag, whole volume")
+
+
 def test_sgm_reference_ones_arange_case(device, oracle):
     """tests/test_semiglobalmatch.py:39-55: ones image, arange volume."""
     import stereomatch
@@ -512,9 +559,10 @@ def test_integration_stub_presents_the_reference_extension_api(device, oracle):
 
 
 # ------------------------------------------------- widest disparity ranges, batched quirks
-@pytest.mark.parametrize("H,W,D", [(6, 10, 1024), (5, 9, 768), (12, 7, 512), (1030, 1040, 1024)][:3])
+@pytest.mark.parametrize("H,W,D", [(6, 10, 1024), (5, 9, 768), (12, 7, 512)])
 def test_largest_disparity_ranges(device, oracle, H, W, D):
-    """D = 512..1024 exercise the 8- and 16-values-per-lane kernels and the 32/64-step DP tiles."""
+    """D = 512..1024 exercise the 8- and 16-values-per-lane kernels (the 32/64-step DP tiles
+    only with fewer than 16 columns: test_dp_wide_tiles covers them properly)."""
     import stereomatch
     rng = np.random.default_rng(D + H)
     C = _random_volume(rng, H, W, D, "float")
@@ -533,6 +581,29 @@ def test_largest_disparity_ranges(device, oracle, H, W, D):
     assert_same_bits(got.cpu().numpy(), oracle.ssd(L, R, D, 7), "ssd")
     bt = stereomatch.cost.Birchfield(D)(_gpu(L, device), _gpu(R, device))
     assert_same_bits(bt.cpu().numpy(), oracle.birchfield(L, R, D), "birchfield")
+
+
+@pytest.mark.parametrize("H,W,D,mode", [
+    (40, 70, 576, "corrected"),    # O = 64: the lane's column wraps (16 columns per period)
+    (30, 50, 384, "corrected"),    # O = 32
+    (9, 100, 1024, "corrected"),   # O = 64, six periods
+    (520, 530, 512, "reference"),  # O = 32 with the transposed initial read and the Q11b clobber
+    (1030, 1040, 1024, "reference"),  # O = 64, the largest reference-mode shape (D <= H <= W)
+])
+def test_dp_wide_tiles(device, oracle, H, W, D, mode):
+    """dp_tile_kernel<32> and <64> on rows longer than one 16-column period, in both modes:
+    path volume, final costs and disparities bit for bit."""
+    import stereomatch
+    rng = np.random.default_rng(D + W)
+    vol = rng.random((H, W, D), dtype=np.float32)
+    vol *= np.float32(50.0)
+    dp = stereomatch.disparity_reduce.DynamicProgramming(mode=mode)
+    got = dp(_gpu(vol, device))
+    want, wpath, wfin = oracle.dp(vol, mode=1 if mode == "corrected" else 0, return_aux=True)
+    assert_same_bits(got.cpu().numpy(), want, "dp %s O-tile" % mode)
+    assert_same_bits(dp.row_final_costs.cpu().numpy(), wfin, "dp row_final")
+    gpath = dp.path_volume.cpu().numpy()
+    assert np.array_equal(gpath, wpath), "dp path volume"
 
 
 @pytest.mark.parametrize("H,W", [(14, 31), (31, 14)])
@@ -599,3 +670,21 @@ def test_graft_entry_smoke_runs(device):
     """The driver's round-end smoke() is exercised here so it cannot drift from the ops."""
     import __graft_entry__ as entry
     entry.smoke()
+
+
+def test_float64_is_declined_with_the_reference_dispatch_named(device):
+    """The reference dispatches float64 for SGM, WTA and DP (AT_DISPATCH_FLOATING_TYPES);
+    the MI355X path is float32 only and says so -- it must not fall back to anything."""
+    import stereomatch
+    vol = torch.zeros(20, 24, 16, dtype=torch.float64, device=device)
+    img = torch.zeros(20, 24, device=device)
+    for call, cite in ((lambda: stereomatch.aggregation.Semiglobal()(vol, img), "semiglobal.cpp:182"),
+                       (lambda: stereomatch.disparity_reduce.WinnerTakesAll()(vol), "winners_take_all.cu:99"),
+                       (lambda: stereomatch.disparity_reduce.DynamicProgramming()(vol),
+                        "dynamic_programming.cu:199")):
+        with pytest.raises(RuntimeError) as e:
+            call()
+        assert "float64" in str(e.value) and cite in str(e.value)
+    # Birchfield casts its images like the reference wrapper (cost.py:98-99): float64 in, float32 out.
+    out = stereomatch.cost.Birchfield(16)(img.double(), img.double())
+    assert out.dtype == torch.float32
