@@ -139,7 +139,30 @@ int stm_birchfield_ex_f32(const float *left, const float *right, float *cost,
  *   STM_SGM_EXACT_NONFINITE  reproduce the reference's placement of NaN and +-inf as well
  *                       (two more selects per element and step: 1-3 % slower). */
 #define STM_SGM_EXACT_NONFINITE 32
+/* Form selection.  By default the library picks per call between the paired form (a wave
+ * per path; any shape) and the tiled form (row sweeps + 8x8-pixel tiles: the cost volume is
+ * read five times, the sum never travels; D = 64, 128 or 256, no ACCUMULATE /
+ * SINGLE_PASSES / EXACT_NONFINITE, and enough columns in the batch to fill the chip).  Same
+ * results bit for bit.
+ *   STM_SGM_PAIRED  never use the tiled form.
+ *   STM_SGM_TILED   use the tiled form whenever it covers the call, whatever the batch size.
+ * Both flags must be passed identically to stm_sgm_workspace_bytes().
+ *
+ * Workspace header: the first 32-bit word of the workspace is a status word, zeroed at the
+ * start of every call that uses the tiled form.  Its row sweeps exchange boundary values
+ * between resident workgroups inside one launch; every such wait is bounded (~2 s), and a
+ * wait that expires sets bit 0 (the results of that call are then invalid).  It can only
+ * happen when the launch's workgroups cannot all be resident (e.g. the device is shared with
+ * another long-running kernel).  The entry points never synchronise, so the word is for the
+ * caller to inspect after its next synchronisation (stm_sgm_status). */
+#define STM_SGM_PAIRED 64
+#define STM_SGM_TILED 128
 size_t stm_sgm_workspace_bytes(int H, int W, int D, int batch, int flags);
+/* Byte offset and meaning of the status word inside a workspace: *(uint32_t*)workspace after
+ * the stream has been synchronised; 0 = ok.  Returns the word's value given a HOST copy of
+ * the workspace's first 4 bytes (a helper for bindings that cannot cast). */
+#define STM_SGM_STATUS_TIMEOUT 1u
+unsigned stm_sgm_status(const void *host_copy_of_first_word);
 int stm_sgm_f32(const float *cost, const float *left, float *out, int H, int W,
                 int D, float penalty1, float penalty2, int flags,
                 void *workspace, size_t workspace_bytes, int batch,

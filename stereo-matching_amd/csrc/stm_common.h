@@ -156,6 +156,16 @@ __device__ __forceinline__ void wave_lds_handoff() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() is a release /
+// acquire pair at workgroup scope over ALL address spaces: hipcc puts s_waitcnt vmcnt(0) in
+// front of the s_barrier, which drains every global load and store the wave has in flight --
+// in a kernel that keeps rows of prefetch outstanding across the barrier that is the whole
+// memory latency, once per barrier.  Here only the LDS counter is drained; the "memory"
+// clobber keeps the compiler from moving LDS (or any) accesses across.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ int wave_uniform(int v) {
   return __builtin_amdgcn_readfirstlane(v);
 }
@@ -238,6 +248,52 @@ template <int VPL, bool VEC, bool NT = false>
 __device__ __forceinline__ void store_row_at(float *__restrict__ base, long off, int D, int d0,
                                              const Row<VPL> &r) {
   store_row<VPL, VEC, NT>(base + off, 0, D, d0, r);
+}
+
+// ---- buffer addressing -------------------------------------------------------------
+// A wave-uniform 128-bit descriptor (base, byte size) in SGPRs, a per-lane 32-bit byte offset
+// and a wave-uniform 32-bit byte offset: a row address costs one scalar add and no vector
+// arithmetic (a 64-bit global address costs a vector 64-bit add per load), small constant
+// parts fold into the instruction.  Regions must be smaller than 4 GiB.
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+__device__ __forceinline__ BufRsrc make_rsrc(const void *base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+template <int VPL>
+__device__ __forceinline__ Row<VPL> buf_load_row(BufRsrc r, int voff, int soff) {
+  Row<VPL> o;
+  if constexpr (VPL == 4) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const v4u q = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    o.v[0] = __builtin_bit_cast(float, q.x); o.v[1] = __builtin_bit_cast(float, q.y);
+    o.v[2] = __builtin_bit_cast(float, q.z); o.v[3] = __builtin_bit_cast(float, q.w);
+  } else if constexpr (VPL == 2) {
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    const v2u q = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    o.v[0] = __builtin_bit_cast(float, q.x); o.v[1] = __builtin_bit_cast(float, q.y);
+  } else {
+    static_assert(VPL == 1, "whole 4-, 8- or 16-byte rows per lane");
+    o.v[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+  }
+  return o;
+}
+template <int VPL>
+__device__ __forceinline__ void buf_store_row(BufRsrc r, int voff, int soff, const Row<VPL> &x) {
+  if constexpr (VPL == 4) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    v4u q;
+    q.x = __builtin_bit_cast(unsigned, x.v[0]); q.y = __builtin_bit_cast(unsigned, x.v[1]);
+    q.z = __builtin_bit_cast(unsigned, x.v[2]); q.w = __builtin_bit_cast(unsigned, x.v[3]);
+    __builtin_amdgcn_raw_buffer_store_b128(q, r, voff, soff, 0);
+  } else if constexpr (VPL == 2) {
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    v2u q;
+    q.x = __builtin_bit_cast(unsigned, x.v[0]); q.y = __builtin_bit_cast(unsigned, x.v[1]);
+    __builtin_amdgcn_raw_buffer_store_b64(q, r, voff, soff, 0);
+  } else {
+    static_assert(VPL == 1, "whole 4-, 8- or 16-byte rows per lane");
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x.v[0]), r, voff, soff, 0);
+  }
 }
 
 #endif  // __HIPCC__

@@ -36,15 +36,17 @@
 // against the algorithmic 8N (read cost once, write sum once).
 #include <type_traits>
 
-#include "stm_common.h"
-
 // This file is compiled twice (csrc/Makefile): as stm_sgm.o with STM_SGM_EXACT = 0, which holds
 // the C entry points, and as stm_sgm_exact.o with STM_SGM_EXACT = 1, which holds the same
 // kernels with the reference's treatment of NaN operands (STM_SGM_EXACT_NONFINITE, see
-// sgm_step) behind stm::sgm_run_exact().
+// sgm_step in stm_sgm_step.h) behind stm::sgm_run_exact().
 #ifndef STM_SGM_EXACT
 #define STM_SGM_EXACT 0
 #endif
+
+#include "stm_common.h"
+#include "stm_sgm_step.h"
+#include "stm_sgm_tiled.h"
 
 namespace stm {
 int sgm_run_exact(const float *cost, const float *left, float *out, int32_t *disp, int H, int W,
@@ -52,7 +54,6 @@ int sgm_run_exact(const float *cost, const float *left, float *out, int32_t *dis
                   size_t workspace_bytes, int batch, void *stream, int final_mode);
 namespace {
 
-constexpr bool kExactNonFinite = STM_SGM_EXACT != 0;
 
 constexpr int kSgmBlock = 256;
 constexpr int kPF = 4;  // pixels kept in flight per wave
@@ -105,7 +106,7 @@ __host__ __device__ inline int sgm_family_paths(int family, int H, int W, bool t
   }
 }
 
-__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+
 
 // Start, direction and length of path `w` of a family, following GeneratePaths and
 // SGPixelPath::inverse() (src/semiglobal.hpp:42-45) entry by entry.
@@ -167,90 +168,6 @@ __device__ __forceinline__ Walk sgm_decode(int family, int w, int H, int W, bool
       break;
   }
   return k;
-}
-
-// P2' of the step between two neighbouring pixels of a path (semiglobal.cpp:137-139):
-// max(P1, P2 / |I(p_i) - I(p_i-1)|).  |a - b| is exactly |b - a|, so a forward and an
-// inverse pass crossing the same pixel boundary use the same value.
-__device__ __forceinline__ float sgm_penalty(float inten, float prev_i, float p1, float p2) {
-  const float q = p2 / fabsf(inten - prev_i);
-  return p1 < q ? q : p1;  // std::max(p1, q)
-}
-
-// A copy of a wave-uniform float that lives in a VGPR (DPP operands must).
-__device__ __forceinline__ float in_vgpr(float x) {
-  asm volatile("" : "+v"(x));
-  return x;
-}
-
-// Per-wave constants and scratch of sgm_step.
-struct StepCtx {
-  float p1, p1v;     // P1 as a scalar and as a VGPR copy (DPP operands must be VGPRs)
-  float below, above;  // DPP results; lane 0 of `below` / lane 63 of `above` stay +inf
-  int d0, dlim;
-  bool drop_tail;    // VEC only (D = 64 * VPL): this lane's last element is d = D-1 and the
-                     // reference minimum leaves it out
-  __device__ __forceinline__ void init(float p1_, int d0_, int dlim_, bool drop_tail_) {
-    p1 = p1_;
-    p1v = in_vgpr(p1_);
-    below = above = in_vgpr(__builtin_inff());
-    d0 = d0_;
-    dlim = dlim_;
-    drop_tail = drop_tail_;
-  }
-};
-
-// One step of the recurrence, pixel i-1 -> pixel i of a path (semiglobal.cpp:129-157).
-// p2a: sgm_penalty of the step (wave-uniform).
-template <int VPL, bool VEC>
-__device__ __forceinline__ Row<VPL> sgm_step(const Row<VPL> &prev, const Row<VPL> &c, float p2a,
-                                             StepCtx &X) {
-  const float inf = __builtin_inff();
-  // m over d in [0, dlim): dlim = D-1 reproduces the reference, whose minimum leaves the
-  // element d = D-1 out (Q5); dlim = D is the corrected full-range minimum.
-  float lm;
-  if constexpr (VEC) {
-    lm = X.drop_tail ? inf : prev.v[VPL - 1];
-#pragma unroll
-    for (int j = 0; j + 1 < VPL - 1; j += 2) lm = vmin3_f32(lm, prev.v[j], prev.v[j + 1]);
-    if constexpr (VPL % 2 == 0) lm = vmin_f32(lm, prev.v[VPL - 2]);
-  } else {
-    lm = inf;
-#pragma unroll
-    for (int j = 0; j < VPL; ++j)
-      if (X.d0 + j < X.dlim) lm = vmin_f32(lm, prev.v[j]);
-  }
-  float m = wave_min_f32(lm);
-  if constexpr (!VEC) {
-    if (X.dlim == 0) m = read_lane(prev.v[0], 0);  // D = 1: empty range, *end() is element D-1
-  }
-  if constexpr (kExactNonFinite) {
-    // std::min_element (cpp:130) is a strict-'<' scan that starts at element 0: a NaN there
-    // is never replaced, a NaN further on never wins.  v_min_f32 ignores NaN operands, which
-    // is the second half of that rule; the first half is this select.
-    const float head = read_lane(prev.v[0], 0);
-    m = (head != head) ? head : m;
-  }
-  const float far = m + p2a;
-  lane_up_add(X.below, prev.v[VPL - 1], X.p1v);  // L(d0-1) + P1
-  lane_down_add(X.above, prev.v[0], X.p1v);      // L(d0+VPL) + P1
-  float w[VPL];
-#pragma unroll
-  for (int j = 0; j < VPL; ++j) w[j] = prev.v[j] + X.p1;
-  Row<VPL> cur;
-#pragma unroll
-  for (int j = 0; j < VPL; ++j) {
-    const float lo = j == 0 ? X.below : w[j - 1];
-    const float hi = j == VPL - 1 ? X.above : w[j + 1];
-    // get_min (cpp:11-16) is a strict-'<' chain; as a value that is the minimum of the
-    // four candidates (v_min3_f32 + v_min_f32).
-    float t = vmin_f32(vmin3_f32(prev.v[j], lo, hi), far);
-    // get_min starts from L(d) and replaces it by a smaller candidate: a NaN L(d) stays.
-    if constexpr (kExactNonFinite) t = (prev.v[j] != prev.v[j]) ? prev.v[j] : t;
-    const float a = c.v[j] + t;
-    cur.v[j] = a - m;
-  }
-  return cur;
 }
 
 // One pass along one path.  FIRST: the output row is overwritten with
@@ -833,7 +750,13 @@ static SgmPlan sgm_plan(int H, int W, int D, int batch, bool paired, bool true_p
 #if !STM_SGM_EXACT
 extern "C" size_t stm_sgm_workspace_bytes(int H, int W, int D, int batch, int flags) {
   if (H <= 0 || W <= 0 || D <= 0 || batch <= 0 || D > STM_MAX_DISPARITY) return 0;
+  if (stm::sgm_tiled_selected(H, W, D, batch, flags))
+    return stm::sgm_tiled_workspace_bytes(H, W, D, batch, flags);
   return sgm_plan(H, W, D, batch, !(flags & STM_SGM_SINGLE_PASSES), (flags & STM_SGM_TRUE_PATHS) != 0).total_floats * sizeof(float);
+}
+
+extern "C" unsigned stm_sgm_status(const void *host_copy_of_first_word) {
+  return host_copy_of_first_word ? *static_cast<const unsigned *>(host_copy_of_first_word) : 0u;
 }
 #endif
 
@@ -904,6 +827,11 @@ static int sgm_run(const float *cost, const float *left, float *out, int32_t *di
   const bool paired = !(flags & STM_SGM_SINGLE_PASSES);
   STM_REQUIRE(final_mode == 0 || (paired && disp), STM_EINVAL,
               "stm_sgm_wta_f32: needs a disparity pointer and the paired form");
+#if !STM_SGM_EXACT
+  if (sgm_tiled_selected(H, W, D, batch, flags))
+    return sgm_run_tiled(cost, left, out, disp, H, W, D, penalty1, penalty2, flags, workspace,
+                         workspace_bytes, batch, as_stream(stream), final_mode);
+#endif
   const bool true_paths = (flags & STM_SGM_TRUE_PATHS) != 0;
   const int dlim = (flags & STM_SGM_FULL_MIN) ? D : D - 1;
   SgmPlan plan = sgm_plan(H, W, D, batch, paired, true_paths);

@@ -1,0 +1,229 @@
+// One step of the semiglobal recurrence for a wave that holds a pixel's disparities in its
+// lanes (VPL consecutive values per lane), shared by every aggregation kernel.
+//
+// Reference: src/semiglobal.cpp:129-157 (SGMCostOperator::operator(), the loop body).
+#pragma once
+
+#include "stm_common.h"
+
+#ifndef STM_SGM_EXACT
+#define STM_SGM_EXACT 0
+#endif
+
+namespace stm {
+namespace {
+
+constexpr bool kExactNonFinite = STM_SGM_EXACT != 0;
+
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+
+// P2' of the step between two neighbouring pixels of a path (semiglobal.cpp:137-139):
+// max(P1, P2 / |I(p_i) - I(p_i-1)|).  |a - b| is exactly |b - a|, so a forward and an
+// inverse pass crossing the same pixel boundary use the same value.
+__device__ __forceinline__ float sgm_penalty(float inten, float prev_i, float p1, float p2) {
+  const float q = p2 / fabsf(inten - prev_i);
+  return p1 < q ? q : p1;  // std::max(p1, q)
+}
+
+// A copy of a wave-uniform float that lives in a VGPR (DPP operands must).
+__device__ __forceinline__ float in_vgpr(float x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+// Per-wave constants and scratch of sgm_step.
+struct StepCtx {
+  float p1, p1v;     // P1 as a scalar and as a VGPR copy (DPP operands must be VGPRs)
+  float below, above;  // DPP results; lane 0 of `below` / lane 63 of `above` stay +inf
+  int d0, dlim;
+  bool drop_tail;    // VEC only (D = 64 * VPL): this lane's last element is d = D-1 and the
+                     // reference minimum leaves it out
+  __device__ __forceinline__ void init(float p1_, int d0_, int dlim_, bool drop_tail_) {
+    p1 = p1_;
+    p1v = in_vgpr(p1_);
+    below = above = in_vgpr(__builtin_inff());
+    d0 = d0_;
+    dlim = dlim_;
+    drop_tail = drop_tail_;
+  }
+};
+
+// One step of the recurrence, pixel i-1 -> pixel i of a path (semiglobal.cpp:129-157).
+// p2a: sgm_penalty of the step (wave-uniform).
+template <int VPL, bool VEC>
+__device__ __forceinline__ Row<VPL> sgm_step(const Row<VPL> &prev, const Row<VPL> &c, float p2a,
+                                             StepCtx &X) {
+  const float inf = __builtin_inff();
+  // m over d in [0, dlim): dlim = D-1 reproduces the reference, whose minimum leaves the
+  // element d = D-1 out (Q5); dlim = D is the corrected full-range minimum.
+  float lm;
+  if constexpr (VEC) {
+    lm = X.drop_tail ? inf : prev.v[VPL - 1];
+#pragma unroll
+    for (int j = 0; j + 1 < VPL - 1; j += 2) lm = vmin3_f32(lm, prev.v[j], prev.v[j + 1]);
+    if constexpr (VPL % 2 == 0) lm = vmin_f32(lm, prev.v[VPL - 2]);
+  } else {
+    lm = inf;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j)
+      if (X.d0 + j < X.dlim) lm = vmin_f32(lm, prev.v[j]);
+  }
+  float m = wave_min_f32(lm);
+  if constexpr (!VEC) {
+    if (X.dlim == 0) m = read_lane(prev.v[0], 0);  // D = 1: empty range, *end() is element D-1
+  }
+  if constexpr (kExactNonFinite) {
+    // std::min_element (cpp:130) is a strict-'<' scan that starts at element 0: a NaN there
+    // is never replaced, a NaN further on never wins.  v_min_f32 ignores NaN operands, which
+    // is the second half of that rule; the first half is this select.
+    const float head = read_lane(prev.v[0], 0);
+    m = (head != head) ? head : m;
+  }
+  const float far = m + p2a;
+  lane_up_add(X.below, prev.v[VPL - 1], X.p1v);  // L(d0-1) + P1
+  lane_down_add(X.above, prev.v[0], X.p1v);      // L(d0+VPL) + P1
+  float w[VPL];
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) w[j] = prev.v[j] + X.p1;
+  Row<VPL> cur;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const float lo = j == 0 ? X.below : w[j - 1];
+    const float hi = j == VPL - 1 ? X.above : w[j + 1];
+    // get_min (cpp:11-16) is a strict-'<' chain; as a value that is the minimum of the
+    // four candidates (v_min3_f32 + v_min_f32).
+    float t = vmin_f32(vmin3_f32(prev.v[j], lo, hi), far);
+    // get_min starts from L(d) and replaces it by a smaller candidate: a NaN L(d) stays.
+    if constexpr (kExactNonFinite) t = (prev.v[j] != prev.v[j]) ? prev.v[j] : t;
+    const float a = c.v[j] + t;
+    cur.v[j] = a - m;
+  }
+  return cur;
+}
+
+
+// ---------------------------------------------------------------------------------
+// N independent steps at once (N = 2 or 3; whole lanes only, D = 64 * VPL).
+//
+// A wave issues in order, and a DPP instruction may read a VGPR only two wait states after
+// the VALU write that produced it, so the six-stage wave minimum of one step spends as many
+// issue slots on s_nop as on v_min.  Steps of different paths are independent: interleaved
+// stage by stage, each chain's next DPP instruction is separated from its producer by the
+// other chains' instructions and (for N = 3) no padding is left at all.  Same instructions
+// per chain, same results.
+// ---------------------------------------------------------------------------------
+template <int N>
+struct StepCtxN {
+  float p1, p1v;
+  float below[N], above[N];  // lane 0 of below[k] / lane 63 of above[k] stay +inf
+  bool drop_tail;
+  __device__ __forceinline__ void init(float p1_, bool drop_tail_) {
+    p1 = p1_;
+    p1v = in_vgpr(p1_);
+#pragma unroll
+    for (int k = 0; k < N; ++k) below[k] = above[k] = in_vgpr(__builtin_inff());
+    drop_tail = drop_tail_;
+  }
+};
+
+#define STM_DPP_MIN(reg, ctrl) "v_min_f32_dpp " reg ", " reg ", " reg " " ctrl "\n\t"
+#define STM_ROW_SHR1 "row_shr:1 row_mask:0xf bank_mask:0xf"
+#define STM_ROW_SHR2 "row_shr:2 row_mask:0xf bank_mask:0xf"
+#define STM_ROW_SHR4 "row_shr:4 row_mask:0xf bank_mask:0xf"
+#define STM_ROW_SHR8 "row_shr:8 row_mask:0xf bank_mask:0xf"
+#define STM_BCAST15 "row_bcast:15 row_mask:0xa bank_mask:0xf"
+#define STM_BCAST31 "row_bcast:31 row_mask:0xc bank_mask:0xf"
+
+// In-place wave minima of two / three registers (lane 63 holds the result, as in
+// wave_min_f32).  The leading s_nop covers a VALU write of the inputs just before.
+__device__ __forceinline__ void wave_min2_f32(float &a, float &b) {
+  asm("s_nop 1\n\t"
+      STM_DPP_MIN("%0", STM_ROW_SHR1) STM_DPP_MIN("%1", STM_ROW_SHR1) "s_nop 0\n\t"
+      STM_DPP_MIN("%0", STM_ROW_SHR2) STM_DPP_MIN("%1", STM_ROW_SHR2) "s_nop 0\n\t"
+      STM_DPP_MIN("%0", STM_ROW_SHR4) STM_DPP_MIN("%1", STM_ROW_SHR4) "s_nop 0\n\t"
+      STM_DPP_MIN("%0", STM_ROW_SHR8) STM_DPP_MIN("%1", STM_ROW_SHR8) "s_nop 0\n\t"
+      STM_DPP_MIN("%0", STM_BCAST15) STM_DPP_MIN("%1", STM_BCAST15) "s_nop 0\n\t"
+      STM_DPP_MIN("%0", STM_BCAST31) "v_min_f32_dpp %1, %1, %1 " STM_BCAST31
+      : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void wave_min3_f32(float &a, float &b, float &c) {
+  asm("s_nop 1\n\t"
+      STM_DPP_MIN("%0", STM_ROW_SHR1) STM_DPP_MIN("%1", STM_ROW_SHR1) STM_DPP_MIN("%2", STM_ROW_SHR1)
+      STM_DPP_MIN("%0", STM_ROW_SHR2) STM_DPP_MIN("%1", STM_ROW_SHR2) STM_DPP_MIN("%2", STM_ROW_SHR2)
+      STM_DPP_MIN("%0", STM_ROW_SHR4) STM_DPP_MIN("%1", STM_ROW_SHR4) STM_DPP_MIN("%2", STM_ROW_SHR4)
+      STM_DPP_MIN("%0", STM_ROW_SHR8) STM_DPP_MIN("%1", STM_ROW_SHR8) STM_DPP_MIN("%2", STM_ROW_SHR8)
+      STM_DPP_MIN("%0", STM_BCAST15) STM_DPP_MIN("%1", STM_BCAST15) STM_DPP_MIN("%2", STM_BCAST15)
+      STM_DPP_MIN("%0", STM_BCAST31) STM_DPP_MIN("%1", STM_BCAST31) "v_min_f32_dpp %2, %2, %2 " STM_BCAST31
+      : "+v"(a), "+v"(b), "+v"(c));
+}
+
+// below[k] = (value of lane - 1 of lo[k]) + p1, above[k] = (value of lane + 1 of hi[k]) + p1
+// for all chains with one leading s_nop (the sources are old registers; the nop covers p1v).
+template <int N>
+__device__ __forceinline__ void lane_shift_adds(float (&below)[N], float (&above)[N], const float (&lo)[N],
+                                                const float (&hi)[N], float p1v) {
+  if constexpr (N == 2) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %4, %8 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %5, %8 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %6, %8 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %7, %8 wave_shl:1 row_mask:0xf bank_mask:0xf"
+        : "+v"(below[0]), "+v"(below[1]), "+v"(above[0]), "+v"(above[1])
+        : "v"(lo[0]), "v"(lo[1]), "v"(hi[0]), "v"(hi[1]), "v"(p1v));
+  } else {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %6, %12 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %7, %12 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %8, %12 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %9, %12 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %10, %12 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %5, %11, %12 wave_shl:1 row_mask:0xf bank_mask:0xf"
+        : "+v"(below[0]), "+v"(below[1]), "+v"(below[2]), "+v"(above[0]), "+v"(above[1]), "+v"(above[2])
+        : "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(p1v));
+  }
+}
+
+// cur[k] = one step (semiglobal.cpp:129-157) from prev[k] into a pixel with costs c[k] and
+// penalty p2a[k], for N independent paths.
+template <int VPL, int N>
+__device__ __forceinline__ void sgm_step_n(const Row<VPL> (&prev)[N], const Row<VPL> (&c)[N],
+                                           const float (&p2a)[N], StepCtxN<N> &X, Row<VPL> (&cur)[N]) {
+  static_assert(N == 2 || N == 3, "two or three chains");
+  const float inf = __builtin_inff();
+  float lm[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    lm[k] = X.drop_tail ? inf : prev[k].v[VPL - 1];
+#pragma unroll
+    for (int j = 0; j + 1 < VPL - 1; j += 2) lm[k] = vmin3_f32(lm[k], prev[k].v[j], prev[k].v[j + 1]);
+    if constexpr (VPL % 2 == 0) lm[k] = vmin_f32(lm[k], prev[k].v[VPL - 2]);
+  }
+  if constexpr (N == 2) wave_min2_f32(lm[0], lm[1]);
+  else wave_min3_f32(lm[0], lm[1], lm[2]);
+  float m[N], far[N], lo[N], hi[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    m[k] = read_lane(lm[k], 63);
+    far[k] = m[k] + p2a[k];
+    lo[k] = prev[k].v[VPL - 1];
+    hi[k] = prev[k].v[0];
+  }
+  lane_shift_adds<N>(X.below, X.above, lo, hi, X.p1v);
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    float w[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) w[j] = prev[k].v[j] + X.p1;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+      const float l = j == 0 ? X.below[k] : w[j - 1];
+      const float h = j == VPL - 1 ? X.above[k] : w[j + 1];
+      const float t = vmin_f32(vmin3_f32(prev[k].v[j], l, h), far[k]);
+      const float a = c[k].v[j] + t;
+      cur[k].v[j] = a - m[k];
+    }
+  }
+}
+
+}  // namespace
+}  // namespace stm

@@ -1,0 +1,22 @@
+// Host-side interface of the tiled form of the semiglobal aggregation (stm_sgm_tiled.hip),
+// used by the C entry points in stm_sgm.hip.
+#pragma once
+
+#include "stm_common.h"
+
+namespace stm {
+
+// Whether the tiled form covers this call (shape, flags, device) and is expected to be the
+// faster one.  Deterministic in its arguments and the current device, so that
+// stm_sgm_workspace_bytes() and stm_sgm_f32() always agree.
+bool sgm_tiled_selected(int H, int W, int D, int batch, int flags);
+
+// Workspace the tiled form needs for this call (0 when it is not selected).
+size_t sgm_tiled_workspace_bytes(int H, int W, int D, int batch, int flags);
+
+// final_mode as in sgm_run (stm_sgm.hip): 0 sum only, 1 sum + disparity, 2 disparity only.
+int sgm_run_tiled(const float *cost, const float *left, float *out, int32_t *disp, int H, int W,
+                  int D, float penalty1, float penalty2, int flags, void *workspace,
+                  size_t workspace_bytes, int batch, hipStream_t stream, int final_mode);
+
+}  // namespace stm

@@ -1,0 +1,1048 @@
+// Semiglobal aggregation, tiled form: the cost volume is read five times and the running
+// sum never travels.
+//
+// Reference semantics: src/semiglobal.cpp:18-91 (path table), :116-159 (recurrence),
+// :191-194 (for each path: run(path); run(path.inverse())) -- see stm_sgm.hip for the
+// restatement.  out(p) = ((((((L> + L<) + Ldown) + Lup) + Ldr) + Lul) + Ldl) + Lur in float,
+// in that order, with the reference's quirks for the two inverse diagonal families (Q6).
+//
+// The paired form (stm_sgm.hip) walks every path per wave: 4 read-only checkpoint walks + 4
+// pair launches, each of which reads the cost volume and read-modify-writes the sum: 56-60
+// bytes per (pixel, disparity).  Here the volume is cut into 8 x 8-pixel tiles:
+//
+//   1. BORDER STATES.  For every direction r, L_r is stored at the pixels where a path leaves a
+//      tile: rows y = 7 (mod 8) for the three downward directions, y = 0 (mod 8) for the three
+//      upward ones, columns x = 7 (mod 8) for the three rightward and x = 0 (mod 8) for the
+//      three leftward ones.  12/8 floats per element in all.  They come from
+//        * sgm_sweep_kernel, down and up: a row sweep in which a wave owns CW image columns
+//          and steps the three directions that advance one row per step (down, down-right,
+//          down-left; or the three upward ones) with ONE read of each cost row.  The
+//          diagonal states move one column per row: between the waves of a workgroup through
+//          LDS (one barrier per row), between workgroups (column strips) through 8-byte
+//          {row tag, value} granules in global memory, written write-through and polled by
+//          the consumer (MI355X guide, Guideline 16, form R2).  All workgroups of a launch
+//          must be resident: the grid is never larger than the CU count, and every wait is
+//          bounded (a timeout sets the status word in the workspace header and the sweep
+//          finishes without waiting again).
+//        * sgm_hwalk_kernel, left-to-right and right-to-left: one wave per image row.
+//   2. TILES.  sgm_tile_kernel: one workgroup per tile loads the tile's cost rows into LDS
+//      once, rebuilds all eight directions inside the tile from the border states (every
+//      path crosses at most 8 pixels of a tile), adds them in the reference order into an
+//      LDS-resident sum tile and writes the finished rows (and/or their winner-takes-all).
+//
+// Traffic per (pixel, d): 5 x 4 (cost reads) + 2 x 6 (border states written and read)
+// + 4 (sum written; 0 with the fused reduction) = 32-36 bytes.
+//
+// Same float operations in the same order as the reference -> identical bits (tested against
+// the oracle and against the paired form).  Covers D = 64, 128, 256 (whole lanes, at most
+// four values per lane: the tile's cost and sum must fit 160 KB of LDS); everything else
+// takes the paired form.
+#include "stm_sgm_tiled.h"
+
+#include <stdlib.h>
+
+#include "stm_sgm_step.h"
+
+namespace stm {
+namespace {
+
+typedef unsigned long long u64;
+
+constexpr int kT = 8;             // tile side, = spacing of the stored border lines
+constexpr int kSweepWaves = 16;   // waves per sweep workgroup (one workgroup per CU)
+constexpr int kMboxSlots = 4;     // granule slots per mailbox (see mbox_* below)
+constexpr unsigned kStatusTimeout = 1u;
+
+// Geometry shared by the three kernels.  All offsets in floats from the workspace base.
+struct TiledGeom {
+  int H, W, D;
+  int nTR, nTC;          // tile rows / columns
+  long long rowb_off;    // [batch][6][nTR][W][D]: down V,A,B (rows y%8==7), up V,A,B (rows y%8==0)
+  long long colb_off;    // [batch][6][nTC][H][D]: ->, dr, ur (columns x%8==7), <-, dl, ul (x%8==0)
+  long long rowb_img, colb_img;
+  long long mbox_off;    // [2 sweeps][batch][strips][2 sides][kMboxSlots][D] granules (u64)
+  int strips;            // column strips per image in the sweeps
+  int batch;
+};
+
+__device__ __forceinline__ float *rowb_ptr(float *ws, const TiledGeom &G, int b, int k, int t, int x) {
+  return ws + G.rowb_off + (long long)b * G.rowb_img +
+         (((long long)k * G.nTR + t) * G.W + x) * (long long)G.D;
+}
+__device__ __forceinline__ float *colb_ptr(float *ws, const TiledGeom &G, int b, int k, int tc, int y) {
+  return ws + G.colb_off + (long long)b * G.colb_img +
+         (((long long)k * G.nTC + tc) * G.H + y) * (long long)G.D;
+}
+
+// ---- granule mailboxes between column strips ---------------------------------------
+// One mailbox carries one pixel's D values of one diagonal direction from the edge wave of a
+// strip to the edge wave of its neighbour, once per image row.  A value and the index of the
+// row it belongs to (+1, never 0) form one naturally aligned 8-byte granule, written by one
+// write-through store: the data is its own flag, the consumer re-reads its granules until
+// every tag matches (no fence on either side).  kMboxSlots = 4 rows of history are enough:
+// a strip that publishes row r has consumed its neighbour's row r-2 and that neighbour is
+// therefore at least in row r-2, where it may still need rows r-3.. of this strip.
+__device__ __forceinline__ u64 *mbox_ptr(float *ws, const TiledGeom &G, int sweep, int b, int strip,
+                                         int side) {
+  u64 *base = reinterpret_cast<u64 *>(ws + G.mbox_off);
+  return base + ((((long long)sweep * G.batch + b) * G.strips + strip) * 2 + side) *
+                    (long long)(kMboxSlots * G.D);
+}
+
+template <int VPL>
+__device__ __forceinline__ void mbox_publish(u64 *box, int D, int d0, unsigned row, const Row<VPL> &r) {
+  u64 *slot = box + (size_t)(row % kMboxSlots) * D + d0;
+  const u64 tag = (u64)(row + 1) << 32;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j)
+    __hip_atomic_store(slot + j, tag | (u64)__builtin_bit_cast(unsigned, r.v[j]), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One polling pass; true when every lane's granules carry the tag of `row`.
+template <int VPL>
+__device__ __forceinline__ bool mbox_try(const u64 *box, int D, int d0, unsigned row, Row<VPL> &r) {
+  const u64 *slot = box + (size_t)(row % kMboxSlots) * D + d0;
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const u64 g = __hip_atomic_load(const_cast<u64 *>(slot) + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ok &= (unsigned)(g >> 32) == row + 1;
+    r.v[j] = __builtin_bit_cast(float, (unsigned)g);
+  }
+  return __ballot(ok) == ~0ull;
+}
+
+// The same pass split in two, so that the loads can be issued a row's worth of work before
+// their result is needed: mbox_peek issues them, mbox_take checks and unpacks.
+template <int VPL>
+struct Granules {
+  u64 g[VPL];
+};
+template <int VPL>
+__device__ __forceinline__ void mbox_peek(const u64 *box, int D, int d0, unsigned row, Granules<VPL> &q) {
+  const u64 *slot = box + (size_t)(row % kMboxSlots) * D + d0;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j)
+    q.g[j] = __hip_atomic_load(const_cast<u64 *>(slot) + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int VPL>
+__device__ __forceinline__ bool mbox_take(const Granules<VPL> &q, unsigned row, Row<VPL> &r) {
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    ok &= (unsigned)(q.g[j] >> 32) == row + 1;
+    r.v[j] = __builtin_bit_cast(float, (unsigned)q.g[j]);
+  }
+  return __ballot(ok) == ~0ull;
+}
+
+// Waits for the neighbour's row `row`.  Bounded: after ~2 s (s_memrealtime runs at 100 MHz)
+// the status word is set and this wave never waits again (`dead`), so the grid always drains.
+template <int VPL>
+__device__ __forceinline__ void mbox_wait(const u64 *box, int D, int d0, unsigned row, Row<VPL> &r,
+                                          bool &dead, unsigned *status) {
+  if (dead) return;
+  if (mbox_try<VPL>(box, D, d0, row, r)) return;
+  const u64 t0 = __builtin_amdgcn_s_memrealtime();
+  for (;;) {
+    __builtin_amdgcn_s_sleep(2);
+    if (mbox_try<VPL>(box, D, d0, row, r)) return;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+      dead = true;
+      if ((threadIdx.x & 63) == 0) atomicOr(status, kStatusTimeout);
+      return;
+    }
+  }
+}
+
+// =====================================================================================
+// Row sweep: three directions per read of the cost volume.
+//
+// DOWN: V = down (0,+1), A = down-right (+1,+1), B = down-left (-1,+1).
+// UP:   V = up (0,-1),   A = up-right (+1,-1),   B = up-left (-1,-1).
+// A moves one column to the right per row (its source is the column on the left), B one to
+// the left.  A wave keeps the three states of its CW columns in registers; in row t it needs
+// A of the column left of its first one and B of the column right of its last one from row
+// t-1: its neighbour waves put them into LDS (double-buffered, one barrier per row), the
+// neighbour workgroups into a mailbox.  What leaves the wave is computed and published first
+// in every row, what arrives is consumed last, so a hand-off has a whole row of slack.
+// =====================================================================================
+struct SweepArgs {
+  TiledGeom G;
+  float p1, p2;
+  int dlim;
+  int b0;  // first image of this launch (blockIdx.y counts from it)
+  long long status_off;
+#ifdef STM_TILE_STAMPS
+  unsigned long long *stamps;  // diagnostic build only: [strip < 8][wave][row 500..515][8]
+#endif
+};
+
+#ifdef STM_TILE_STAMPS
+#define STM_SWEEP_STAMP(k)                                                                   \
+  do {                                                                                       \
+    if (P.stamps && !UP && blockIdx.y == 0 && s < 8 && t >= 500 && t < 516 && lane == 0) {   \
+      unsigned long long t_;                                                                 \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
+      P.stamps[(((size_t)s * NW + wv) * 16 + (t - 500)) * 8 + (k)] = t_;                     \
+    }                                                                                        \
+  } while (0)
+#else
+#define STM_SWEEP_STAMP(k) do {} while (0)
+#endif
+
+template <int VPL, int CW, bool UP>
+__global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float *__restrict__ cost_all,
+                                                                    const float *__restrict__ image_all,
+                                                                    float *__restrict__ ws,
+                                                                    const SweepArgs P) {
+  static_assert(CW >= 2, "a wave's leaving states must not depend on its arriving ones");
+  constexpr int PF = 2;  // cost rows in flight beyond the current one
+  constexpr int NW = kSweepWaves;
+  constexpr int D = 64 * VPL;
+  __shared__ __attribute__((aligned(16))) float xch[2][2][NW][D];  // [parity][A/B][wave][d]
+  const TiledGeom &G = P.G;
+  const int lane = threadIdx.x & 63;
+  const int wv = wave_uniform((int)(threadIdx.x >> 6));
+  const int s = blockIdx.x;
+  const int b = P.b0 + (int)blockIdx.y;
+  const int H = G.H, W = G.W;
+  const int d0 = lane * VPL;
+  const int xa = (s * NW + wv) * CW;  // this wave's first column
+  const bool active = xa < W;
+  const size_t npix = (size_t)H * W;
+  const float *cost = cost_all + (size_t)b * npix * D;
+  const float *image = image_all + (size_t)b * npix;
+  unsigned *status = reinterpret_cast<unsigned *>(ws + P.status_off);
+  StepCtxN<3> X;
+  X.init(P.p1, lane == 63 && P.dlim < D);
+
+  // Neighbours.  Left source of column xa: none at the image border (the path starts there).
+  const bool has_left = xa > 0, left_lds = wv > 0;
+  const bool has_right = xa + CW < W, right_lds = wv < NW - 1;
+  const int sweep = UP ? 1 : 0;
+  u64 *pubA = (has_right && !right_lds) ? mbox_ptr(ws, G, sweep, b, s, 0) : nullptr;
+  u64 *pubB = (has_left && !left_lds) ? mbox_ptr(ws, G, sweep, b, s, 1) : nullptr;
+  const u64 *subA = (has_left && !left_lds) ? mbox_ptr(ws, G, sweep, b, s - 1, 0) : nullptr;
+  const u64 *subB = (has_right && !right_lds) ? mbox_ptr(ws, G, sweep, b, s + 1, 1) : nullptr;
+  bool dead = false;
+
+  // Element offsets (32-bit, wave-uniform) of this wave's columns in row 0; a wave at the right
+  // border may own fewer than CW columns and re-reads its last one for the others.
+  int xoff[CW];
+#pragma unroll
+  for (int j = 0; j < CW; ++j) xoff[j] = imin(xa + j, W - 1) * D;
+  const int row_elems = W * D;
+  auto row_of = [&](int t) { return UP ? H - 1 - t : t; };
+  auto fetch = [&](int t, Row<VPL> (&dst)[CW]) {
+    const int base = wave_uniform(row_of(imin(t, H - 1)) * row_elems);
+#pragma unroll
+    for (int j = 0; j < CW; ++j) dst[j] = load_row_at<VPL, true>(cost, (long)(unsigned)(base + xoff[j]), D, d0);
+  };
+  // Intensities for the 3*CW penalties of a row: lane l serves column l/3, direction l%3
+  // (0 V, 1 A, 2 B) and reads its pixel and that pixel's predecessor on the path.
+  const int pj = imin(lane / 3, CW - 1), pk = lane % 3;
+  const int px = imin(xa + pj, W - 1);
+  const int pxs = pk == 1 ? (px > 0 ? px - 1 : 0) : (pk == 2 ? imin(px + 1, W - 1) : px);
+  auto fetch_intensity = [&](int t, float &icur, float &iprev) {
+    const int tt = imin(t, H - 1);
+    const int y = row_of(tt), yp = row_of(tt > 0 ? tt - 1 : 0);
+    icur = image[(size_t)y * W + px];
+    iprev = image[(size_t)yp * W + pxs];
+  };
+
+  // Where this wave's column states go: at most one column with x % 8 == 7 (A) and one with
+  // x % 8 == 0 (B) per eight columns.
+  Row<VPL> V[CW], A[CW], B[CW];
+  // Vector-memory results come back in issue order, so every row issues its loads in the
+  // order in which later rows consume them: [intensities and cost rows of row t + PF + 1]
+  // [at the row's end: what the neighbour strips have published for the next row].
+  Row<VPL> cb[PF + 1][CW];
+  float ic[PF + 1], ip[PF + 1];
+  Granules<VPL> qa, qb;
+
+  if (active) {
+#pragma unroll
+    for (int u = 0; u <= PF; ++u) {
+      fetch_intensity(u, ic[u], ip[u]);
+      fetch(u, cb[u]);
+    }
+  }
+  for (int t0 = 0; t0 < H; t0 += PF + 1) {
+#pragma unroll
+    for (int u = 0; u <= PF; ++u) {
+      const int t = t0 + u;
+      if (t < H) {
+        const int y = row_of(t);
+        const int par = t & 1;
+        STM_SWEEP_STAMP(0);
+        if (active) {
+          Row<VPL> c[CW];
+#pragma unroll
+          for (int j = 0; j < CW; ++j) c[j] = cb[u][j];
+          const float pen = sgm_penalty(ic[u], ip[u], P.p1, P.p2);
+          fetch_intensity(t + PF + 1, ic[u], ip[u]);
+          fetch(t + PF + 1, cb[u]);
+          if (t == 0) {
+#pragma unroll
+            for (int j = 0; j < CW; ++j) { V[j] = c[j]; A[j] = c[j]; B[j] = c[j]; }
+            if (pubA) mbox_publish<VPL>(pubA, D, d0, 0u, A[CW - 1]);
+            if (pubB) mbox_publish<VPL>(pubB, D, d0, 0u, B[0]);
+            store_row<VPL, true>(&xch[par][0][wv][0], 0, D, d0, A[CW - 1]);
+            store_row<VPL, true>(&xch[par][1][wv][0], 0, D, d0, B[0]);
+          } else {
+            // CW batches of three independent steps: batch i steps A into column CW-1-i (from
+            // the column on its left), B into column i (from the column on its right) and V in
+            // column i.  In place: every state is read by an earlier batch than the one that
+            // overwrites it.  Batch 0 produces what leaves the wave (A of the last column, B of
+            // the first) and needs nothing from outside; the last batch consumes what arrives.
+#pragma unroll
+            for (int i = 0; i < CW; ++i) {
+              const int ja = CW - 1 - i, jb = i;
+              Row<VPL> prev[3], cc[3], cur[3];
+              prev[0] = V[i];
+              cc[0] = c[i];
+              cc[1] = c[ja];
+              cc[2] = c[jb];
+              if (i < CW - 1) {
+                prev[1] = A[ja - 1];
+                prev[2] = B[jb + 1];
+              } else {
+                STM_SWEEP_STAMP(2);
+                // What arrives: A for the first column, B for the last.
+                if (has_left) {
+                  if (left_lds) prev[1] = load_row<VPL, true>(&xch[par ^ 1][0][wv - 1][0], 0, D, d0);
+                  else if (dead || !mbox_take<VPL>(qa, (unsigned)(t - 1), prev[1]))
+                    mbox_wait<VPL>(subA, D, d0, (unsigned)(t - 1), prev[1], dead, status);
+                } else {
+                  prev[1] = c[0];
+                }
+                if (has_right) {
+                  if (right_lds) prev[2] = load_row<VPL, true>(&xch[par ^ 1][1][wv + 1][0], 0, D, d0);
+                  else if (dead || !mbox_take<VPL>(qb, (unsigned)(t - 1), prev[2]))
+                    mbox_wait<VPL>(subB, D, d0, (unsigned)(t - 1), prev[2], dead, status);
+                } else {
+                  prev[2] = c[CW - 1];
+                }
+              }
+              if (i == CW - 1) STM_SWEEP_STAMP(3);
+              const float p2a[3] = {read_lane(pen, 3 * i), read_lane(pen, 3 * ja + 1),
+                                    read_lane(pen, 3 * jb + 2)};
+              sgm_step_n<VPL, 3>(prev, cc, p2a, X, cur);
+              V[i] = cur[0];
+              // A path starts in image column 0, a B path in column W-1 (L = C there).
+              A[ja] = (xa + ja == 0) ? c[ja] : cur[1];
+              B[jb] = (xa + jb >= W - 1) ? c[jb] : cur[2];
+              if (i == 0) {
+                if (pubA) mbox_publish<VPL>(pubA, D, d0, (unsigned)t, A[CW - 1]);
+                if (pubB) mbox_publish<VPL>(pubB, D, d0, (unsigned)t, B[0]);
+                store_row<VPL, true>(&xch[par][0][wv][0], 0, D, d0, A[CW - 1]);
+                store_row<VPL, true>(&xch[par][1][wv][0], 0, D, d0, B[0]);
+                STM_SWEEP_STAMP(1);
+              }
+            }
+          }
+          STM_SWEEP_STAMP(4);
+          // What the neighbour strips published in THIS row (at its start, a row's work ago)
+          // is requested now and looked at at the end of the next row: a poll from a CU that
+          // streams cost rows queues behind them for microseconds, a whole row hides that.
+          if (!dead && t + 1 < H) {
+            if (subA) mbox_peek<VPL>(subA, D, d0, (unsigned)t, qa);
+            if (subB) mbox_peek<VPL>(subB, D, d0, (unsigned)t, qb);
+          }
+          // Border states.  Row lines: every column of this wave; column lines: A where a
+          // rightward path leaves a tile (x % 8 == 7), B where a leftward one does (x % 8 == 0).
+          if ((y & (kT - 1)) == (UP ? 0 : kT - 1)) {
+#pragma unroll
+            for (int j = 0; j < CW; ++j) {
+              if (xa + j < W) {
+                float *r0 = rowb_ptr(ws, G, b, UP ? 3 : 0, y >> 3, xa + j);
+                const long long kstride = (long long)G.nTR * G.W * D;
+                store_row<VPL, true>(r0, 0, D, d0, V[j]);
+                store_row<VPL, true>(r0 + kstride, 0, D, d0, A[j]);
+                store_row<VPL, true>(r0 + 2 * kstride, 0, D, d0, B[j]);
+              }
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < CW; ++j) {
+            const int x = xa + j;
+            if (x < W && (x & (kT - 1)) == kT - 1)
+              store_row<VPL, true>(colb_ptr(ws, G, b, UP ? 2 : 1, x >> 3, y), 0, D, d0, A[j]);
+            if (x < W && (x & (kT - 1)) == 0)
+              store_row<VPL, true>(colb_ptr(ws, G, b, UP ? 5 : 4, x >> 3, y), 0, D, d0, B[j]);
+          }
+        }
+        // One barrier per row: xch[par] written in this row is read in the next one, and
+        // xch[par ^ 1] read in this row is rewritten in the next one.
+        STM_SWEEP_STAMP(5);
+        lds_barrier();
+        STM_SWEEP_STAMP(6);
+      }
+    }
+  }
+}
+
+// =====================================================================================
+// Horizontal walks: one wave per image row and direction; the state is kept where the path
+// leaves a tile (x % 8 == 7 going right, x % 8 == 0 going left).
+// =====================================================================================
+struct HwalkArgs {
+  TiledGeom G;
+  float p1, p2;
+  int dlim;
+};
+
+template <int VPL>
+__global__ __launch_bounds__(256) void sgm_hwalk_kernel(const float *__restrict__ cost_all,
+                                                        const float *__restrict__ image_all,
+                                                        float *__restrict__ ws, const HwalkArgs P) {
+  constexpr int PF = 8;
+  constexpr int D = 64 * VPL;
+  const TiledGeom &G = P.G;
+  const int lane = threadIdx.x & 63;
+  int wave = wave_uniform((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int H = G.H, W = G.W;
+  if (wave >= 2 * H * G.batch) return;
+  const bool left = wave & 1;  // 0: left-to-right, 1: right-to-left
+  wave >>= 1;
+  const int b = wave / H, y = wave - b * H;
+  const int d0 = lane * VPL;
+  const float *cost = cost_all + ((size_t)b * H + y) * (size_t)W * D;
+  const float *image = image_all + ((size_t)b * H + y) * (size_t)W;
+  StepCtx X;
+  X.init(P.p1, d0, P.dlim, lane == 63 && P.dlim < D);
+  const int last = W - 1;
+  auto col_of = [&](int i) { return left ? last - i : i; };
+
+  // Penalties of 64 steps at a time (as in sgm_ckpt_kernel): lane l holds step i0 + l.
+  float na = image[col_of(0)], nb, pen = 0.0f;
+  auto pen_inputs = [&](int i0) {
+    const float carry = read_lane(na, kWave - 1);
+    na = image[col_of(imin(i0 + lane, last))];
+    nb = lane_up(na, carry);
+  };
+  pen_inputs(0);
+
+  Row<VPL> cbuf[PF];
+#pragma unroll
+  for (int u = 0; u < PF; ++u) cbuf[u] = load_row<VPL, true>(cost, (size_t)col_of(imin(u, last)), D, d0);
+  Row<VPL> prev = cbuf[0];
+  const int keep = left ? 0 : kT - 1;
+  const int k = left ? 3 : 0;
+  for (int base = 0; base < W; base += PF) {
+    if ((base & (kWave - 1)) == 0) {
+      pen = sgm_penalty(na, nb, P.p1, P.p2);
+      pen_inputs(base + kWave);
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int i = base + u;
+      if (i < W) {
+        const Row<VPL> c = cbuf[u];
+        cbuf[u] = load_row<VPL, true>(cost, (size_t)col_of(imin(i + PF, last)), D, d0);
+        if (i > 0) prev = sgm_step<VPL, true>(prev, c, read_lane(pen, i & (kWave - 1)), X);
+        const int x = col_of(i);
+        if ((x & (kT - 1)) == keep) store_row<VPL, true>(colb_ptr(ws, G, b, k, x >> 3, y), 0, D, d0, prev);
+      }
+    }
+  }
+}
+
+// =====================================================================================
+// Tiles.
+//
+// Directions: 0 right, 1 left, 2 down, 3 up, 4 down-right, 5 up-left, 6 down-left, 7 up-right;
+// phase p handles the pair (2p, 2p+1), a direction F and its inverse I, in the reference's
+// order.  In a phase wave w owns up to two segments of F-paths inside the tile: row w, column
+// w, or the two diagonals w and w + 8 (of 15), which together have 8 pixels.  Their pixels
+// fill 8 "slots" in F order; the F chain runs through the slots upwards and the I chain
+// downwards at the same time (independent dependency chains), restarting from a border
+// state, or from L = C at the image border, where a segment begins.  Then every slot's sum is
+// updated once: S = ((S + [I x pre]) + F) + I x count, the bracket and count != 1 only on the
+// diagonals the reference re-walks or skips (Q6).
+// =====================================================================================
+struct TileArgs {
+  TiledGeom G;
+  float p1, p2;
+  int dlim;
+  int true_paths;
+#ifdef STM_TILE_STAMPS
+  unsigned long long *stamps;  // diagnostic build only: [tile][wave][8] s_memtime stamps
+#endif
+};
+
+#ifdef STM_TILE_STAMPS
+// Diagnostic build (tools/tile_stamps.py): where a tile's time goes.  Never in the product.
+#define STM_STAMP(k)                                                                        \
+  do {                                                                                      \
+    if (P.stamps && b == 0 && tile < 4096 && lane == 0) {                                   \
+      unsigned long long t_;                                                                \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+      P.stamps[((size_t)tile * 16 + w16) * 8 + (k)] = t_;                                   \
+    }                                                                                       \
+  } while (0)
+#else
+#define STM_STAMP(k) do {} while (0)
+#endif
+
+struct Seg {
+  int ex, ey, n;  // first pixel in F order (tile coordinates) and pixel count
+};
+struct PhaseGeom {
+  Seg a, b;
+};
+
+template <int PHASE>
+__device__ __forceinline__ Seg tile_line(int k, int tw, int th) {
+  Seg s;
+  if (PHASE == 0) { s.ex = 0; s.ey = k; s.n = k < th ? tw : 0; }
+  else if (PHASE == 1) { s.ex = k; s.ey = 0; s.n = k < tw ? th : 0; }
+  else if (PHASE == 2) {  // x - y = k - 7, walked (+1, +1)
+    const int c = k - (kT - 1);
+    const int xlo = c > 0 ? c : 0, xhi = imin(tw - 1, th - 1 + c);
+    s.ex = xlo; s.ey = xlo - c; s.n = xhi >= xlo ? xhi - xlo + 1 : 0;
+  } else {                // x + y = k, walked (-1, +1)
+    const int xlo = k - th + 1 > 0 ? k - th + 1 : 0, xhi = imin(tw - 1, k);
+    s.ex = xhi; s.ey = k - xhi; s.n = xhi >= xlo ? xhi - xlo + 1 : 0;
+  }
+  if (s.n <= 0) { s.ex = 0; s.ey = 0; s.n = 0; }
+  return s;
+}
+
+template <int PHASE>
+__device__ __forceinline__ PhaseGeom tile_geom(int w, int tw, int th) {
+  PhaseGeom g;
+  g.a = tile_line<PHASE>(w, tw, th);
+  if (PHASE >= 2 && w < kT - 1) g.b = tile_line<PHASE>(w + kT, tw, th);
+  else { g.b.ex = 0; g.b.ey = 0; g.b.n = 0; }
+  // Keep the slots dense: an empty first segment hands its place to the second.
+  if (g.a.n == 0) { g.a = g.b; g.b.n = 0; }
+  return g;
+}
+
+// State of direction `dir` after pixel (gx, gy), which lies on one of the stored lines.
+__device__ __forceinline__ const float *border_ptr(float *ws, const TiledGeom &G, int b, int dir,
+                                                   int gx, int gy) {
+  switch (dir) {
+    case 0: return colb_ptr(ws, G, b, 0, gx >> 3, gy);
+    case 1: return colb_ptr(ws, G, b, 3, gx >> 3, gy);
+    case 2: return rowb_ptr(ws, G, b, 0, gy >> 3, gx);
+    case 3: return rowb_ptr(ws, G, b, 3, gy >> 3, gx);
+    case 4: return (gy & 7) == 7 ? rowb_ptr(ws, G, b, 1, gy >> 3, gx) : colb_ptr(ws, G, b, 1, gx >> 3, gy);
+    case 5: return (gy & 7) == 0 ? rowb_ptr(ws, G, b, 5, gy >> 3, gx) : colb_ptr(ws, G, b, 5, gx >> 3, gy);
+    case 6: return (gy & 7) == 7 ? rowb_ptr(ws, G, b, 2, gy >> 3, gx) : colb_ptr(ws, G, b, 4, gx >> 3, gy);
+    default: return (gy & 7) == 0 ? rowb_ptr(ws, G, b, 4, gy >> 3, gx) : colb_ptr(ws, G, b, 2, gx >> 3, gy);
+  }
+}
+
+template <int PHASE>
+struct PhaseDir {
+  static constexpr int dx = PHASE == 0 ? 1 : (PHASE == 1 ? 0 : (PHASE == 2 ? 1 : -1));
+  static constexpr int dy = PHASE == 0 ? 0 : 1;
+};
+
+// The four entry states of a wave's phase: [0] F of segment a, [1] I of a, [2] F of b, [3] I
+// of b.  Bit i of `start` set: the path begins at that pixel (L = C), nothing is loaded.
+template <int VPL>
+struct Entries {
+  Row<VPL> e[4];
+  unsigned start;
+};
+
+template <int VPL, int PHASE>
+__device__ __forceinline__ void load_entries(Entries<VPL> &E, const PhaseGeom &g, float *ws,
+                                             const TiledGeom &G, int b, int x0, int y0, int d0) {
+  constexpr int dx = PhaseDir<PHASE>::dx, dy = PhaseDir<PHASE>::dy;
+  constexpr int D = 64 * VPL;
+  E.start = 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const Seg &s = i == 0 ? g.a : g.b;
+    const int fx = x0 + s.ex - dx, fy = y0 + s.ey - dy;
+    const int ix = x0 + s.ex + s.n * dx, iy = y0 + s.ey + s.n * dy;
+    const bool fin = s.n > 0 && fx >= 0 && fx < G.W && fy >= 0 && fy < G.H;
+    const bool iin = s.n > 0 && ix >= 0 && ix < G.W && iy >= 0 && iy < G.H;
+    if (fin) E.e[2 * i] = load_row<VPL, true>(border_ptr(ws, G, b, 2 * PHASE, fx, fy), 0, D, d0);
+    else E.start |= 1u << (2 * i);
+    if (iin) E.e[2 * i + 1] = load_row<VPL, true>(border_ptr(ws, G, b, 2 * PHASE + 1, ix, iy), 0, D, d0);
+    else E.start |= 2u << (2 * i);
+    if (!fin) {
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) E.e[2 * i].v[j] = 0.0f;
+    }
+    if (!iin) {
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) E.e[2 * i + 1].v[j] = 0.0f;
+    }
+  }
+}
+
+// How often the inverse pass of a diagonal is added (and, on tall images, how often before
+// the forward pass), following the reference's stored path ends (stm_sgm.hip, sgm_decode).
+struct Counts {
+  int inv, pre;
+};
+template <int PHASE>
+__device__ __forceinline__ Counts seg_counts(const Seg &s, int x0, int y0, const TiledGeom &G,
+                                             int true_paths) {
+  Counts c;
+  c.inv = 1;
+  c.pre = 0;
+  if (PHASE < 2 || true_paths || s.n == 0) return c;
+  const int e = G.W - G.H;
+  const int gx = x0 + s.ex, gy = y0 + s.ey;
+  if (PHASE == 2) {
+    const int dgn = gx - gy;
+    if (e > 0) {
+      if (dgn >= 0 && dgn < e) c.inv = 0;
+      else if (dgn == e) c.inv = 1 + e;
+    } else if (e < -1) {
+      if (dgn > e && dgn < 0) c.inv = 0;
+      else if (dgn == e) c.pre = -e - 1;
+    }
+  } else if (e > 0) {
+    const int sum = gx + gy;
+    if (sum >= G.H && sum <= G.W - 1) c.inv = 0;
+    else if (sum == G.H - 1) c.inv = 1 + e;
+  }
+  return c;
+}
+
+template <int VPL>
+__device__ __forceinline__ Row<VPL> lds_row(const float *tile, int pix, int d0) {
+  return load_row<VPL, true>(tile + (size_t)pix * (64 * VPL), 0, 64 * VPL, d0);
+}
+
+// The slots of a wave's phase: pixel index (y * 8 + x, tile coordinates) of every slot.
+template <int PHASE>
+struct Slots {
+  int pix[kT];
+  int nA, nT;
+  __device__ __forceinline__ void init(const PhaseGeom &g) {
+    constexpr int dx = PhaseDir<PHASE>::dx, dy = PhaseDir<PHASE>::dy;
+    nA = g.a.n;
+    nT = g.a.n + g.b.n;
+#pragma unroll
+    for (int s = 0; s < kT; ++s) {
+      const bool in_a = s < nA;
+      const int k = in_a ? s : s - nA;
+      const int x = (in_a ? g.a.ex : g.b.ex) + k * dx, y = (in_a ? g.a.ey : g.b.ey) + k * dy;
+      pix[s] = s < nT ? y * kT + x : 0;
+    }
+  }
+};
+
+// Both chains of a phase: LF[s] / LI[s] = L of the forward / inverse direction at slot s.
+template <int VPL, int PHASE>
+__device__ __forceinline__ void tile_chains(const Slots<PHASE> &sl, const Entries<VPL> &E, const float *Ct,
+                                            const float *Ip, float p1, float p2, StepCtx &X, int lane,
+                                            Row<VPL> (&LF)[kT], Row<VPL> (&LI)[kT]) {
+  constexpr int dx = PhaseDir<PHASE>::dx, dy = PhaseDir<PHASE>::dy;
+  const int d0 = lane * VPL;
+  const int nA = sl.nA, nT = sl.nT;
+  if (nT == 0) return;
+  // Penalties: lane s (0..7) the step into slot s on the F chain (from its predecessor),
+  // lane 8 + s the step into slot s on the I chain (from its successor).
+  float pen;
+  {
+    const int s = imin(lane & 7, nT - 1);
+    const bool inv = (lane >> 3) & 1;
+    int pix = sl.pix[0];
+#pragma unroll
+    for (int k = 1; k < kT; ++k) pix = s == k ? sl.pix[k] : pix;
+    const int px = pix & (kT - 1), py = pix >> 3;
+    const int qx = px + (inv ? dx : -dx), qy = py + (inv ? dy : -dy);
+    pen = sgm_penalty(Ip[(py + 1) * (kT + 2) + px + 1], Ip[(qy + 1) * (kT + 2) + qx + 1], p1, p2);
+  }
+  Row<VPL> pf = E.e[0], pi = E.e[1];
+#pragma unroll
+  for (int it = 0; it < kT; ++it) {
+    {  // F chain, slot it
+      const int s = it;
+      if (s < nT) {
+        const Row<VPL> c = lds_row<VPL>(Ct, sl.pix[s], d0);
+        bool start = false;
+        if (s == 0) {
+          start = (E.start & 1u) != 0;
+        } else if (PHASE >= 2 && s == nA) {  // the second diagonal begins
+          pf = E.e[2];
+          start = (E.start & 4u) != 0;
+        }
+        Row<VPL> cur = sgm_step<VPL, true>(pf, c, read_lane(pen, s), X);
+        if ((s == 0 || PHASE >= 2) && start) cur = c;
+        LF[s] = cur;
+        pf = cur;
+      }
+    }
+    {  // I chain, slot 7 - it
+      const int s = kT - 1 - it;
+      if (s < nT) {
+        const Row<VPL> c = lds_row<VPL>(Ct, sl.pix[s], d0);
+        bool start = false;
+        if (s == nT - 1) {
+          const bool seg_b = PHASE >= 2 && s >= nA;
+          if (seg_b) pi = E.e[3];
+          start = (E.start & (seg_b ? 8u : 2u)) != 0;
+        } else if (PHASE >= 2 && s == nA - 1) {  // back in the first diagonal
+          pi = E.e[1];
+          start = (E.start & 2u) != 0;
+        }
+        Row<VPL> cur = sgm_step<VPL, true>(pi, c, read_lane(pen, 8 + s), X);
+        if (start) cur = c;
+        LI[s] = cur;
+        pi = cur;
+      }
+    }
+  }
+}
+
+// The phase's update of the sum tile: S = ((S + [I x pre]) + F) + I x count per slot.
+template <int VPL, int PHASE, int FINAL>
+__device__ __forceinline__ void tile_add(const PhaseGeom &g, const Slots<PHASE> &sl, const Row<VPL> (&LF)[kT],
+                                         const Row<VPL> (&LI)[kT], float *St, const TileArgs &P, int x0,
+                                         int y0, float *__restrict__ out, int32_t *__restrict__ disp,
+                                         int lane) {
+  constexpr int D = 64 * VPL;
+  const int d0 = lane * VPL;
+  const int nA = sl.nA, nT = sl.nT;
+  if (nT == 0) return;
+  const Counts ca = seg_counts<PHASE>(g.a, x0, y0, P.G, P.true_paths);
+  const Counts cb = seg_counts<PHASE>(g.b, x0, y0, P.G, P.true_paths);
+#pragma unroll
+  for (int s = 0; s < kT; ++s) {
+    if (s < nT) {
+      const int pix = sl.pix[s];
+      Row<VPL> acc;
+      if (PHASE == 0) {
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) acc.v[j] = 0.0f;
+      } else {
+        acc = lds_row<VPL>(St, pix, d0);
+      }
+      if (PHASE == 2) {
+        const int pre = s < nA ? ca.pre : cb.pre;
+        for (int r = 0; r < pre; ++r) {
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) acc.v[j] = acc.v[j] + LI[s].v[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) acc.v[j] = acc.v[j] + LF[s].v[j];
+      if (PHASE < 2) {
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) acc.v[j] = acc.v[j] + LI[s].v[j];
+      } else {
+        const int inv = s < nA ? ca.inv : cb.inv;
+        for (int r = 0; r < inv; ++r) {
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) acc.v[j] = acc.v[j] + LI[s].v[j];
+        }
+      }
+      if (PHASE < 3) {
+        store_row<VPL, true>(St + (size_t)pix * D, 0, D, d0, acc);
+      } else {
+        const size_t q = (size_t)(y0 + (pix >> 3)) * P.G.W + (x0 + (pix & (kT - 1)));
+        if (FINAL != 2) store_row<VPL, true>(out, q, D, d0, acc);
+        if (FINAL != 0) {
+          // Winner takes all (src/winners_take_all.cu:21-40): strict-'<' scan in register
+          // order, then the lowest lane among those holding the wave minimum; a NaN at d = 0
+          // wins, as in the reference scan.
+          float best = __builtin_inff();
+          int idx = d0;
+#pragma unroll
+          for (int j = 0; j < VPL; ++j)
+            if (acc.v[j] < best) { best = acc.v[j]; idx = d0 + j; }
+          const float m = wave_min_f32(best);
+          const int win = __builtin_amdgcn_readlane(idx, __builtin_ctzll(__ballot(best == m)));
+          const float first = read_lane(acc.v[0], 0);
+          if (lane == 0) disp[q] = (first != first) ? 0 : win;
+        }
+      }
+    }
+  }
+}
+
+// Sixteen waves per tile in two groups of eight: group 0 handles the direction pairs 0
+// (right/left) and 2 (down-right/up-left), group 1 the pairs 1 (down/up) and 3
+// (down-left/up-right).  The chains of a pair only read the cost tile, so the two groups run
+// them at the same time; only the four updates of the sum tile are serialised (barriers B1-B3),
+// in the reference's order:
+//   group 0: chains 0, add 0 | B1 | chains 2        | B2 | add 2    | B3 |
+//   group 1: chains 1        | B1 | add 1           | B2 | chains 3 | B3 | add 3
+template <int VPL, int FINAL>
+__global__ __launch_bounds__(2 * kT * 64) void sgm_tile_kernel(const float *__restrict__ cost_all,
+                                                               const float *__restrict__ image_all,
+                                                               float *__restrict__ out_all,
+                                                               int32_t *__restrict__ disp_all,
+                                                               float *__restrict__ ws, const TileArgs P) {
+  constexpr int D = 64 * VPL;
+  __shared__ __attribute__((aligned(16))) float Ct[kT * kT * D];
+  __shared__ __attribute__((aligned(16))) float St[kT * kT * D];
+  __shared__ float Ip[(kT + 2) * (kT + 2)];
+  const TiledGeom &G = P.G;
+  const int lane = threadIdx.x & 63;
+  const int w16 = wave_uniform((int)(threadIdx.x >> 6));
+  const int grp = w16 >> 3, w = w16 & (kT - 1);
+  const int d0 = lane * VPL;
+  const int tile = blockIdx.x;
+  const int b = blockIdx.y;
+  const int trow = tile / G.nTC, tcol = tile - trow * G.nTC;
+  const int x0 = tcol * kT, y0 = trow * kT;
+  const int tw = imin(kT, G.W - x0), th = imin(kT, G.H - y0);
+  const size_t npix = (size_t)G.H * G.W;
+  const float *cost = cost_all + (size_t)b * npix * D;
+  const float *image = image_all + (size_t)b * npix;
+  float *out = out_all ? out_all + (size_t)b * npix * D : nullptr;
+  int32_t *disp = disp_all ? disp_all + (size_t)b * npix : nullptr;
+  StepCtx X;
+  X.init(P.p1, d0, P.dlim, lane == 63 && P.dlim < D);
+
+  STM_STAMP(0);
+  // The tile's cost rows: wave w16 brings half of tile row w16 / 2.
+  constexpr int HC = kT / 2;
+  const int lr = w16 >> 1, lc = (w16 & 1) * HC;
+  Row<VPL> crow[HC];
+  if (lr < th) {
+#pragma unroll
+    for (int c = 0; c < HC; ++c)
+      crow[c] = load_row<VPL, true>(cost, (size_t)(y0 + lr) * G.W + x0 + imin(lc + c, tw - 1), D, d0);
+  }
+  // Intensities of the tile and the ring of pixels around it (clamped at the image border;
+  // a clamped sample is only ever used for a step that does not exist).
+  if (threadIdx.x < (kT + 2) * (kT + 2)) {
+    const int r = (int)threadIdx.x / (kT + 2) - 1, c = (int)threadIdx.x % (kT + 2) - 1;
+    const int gy = imin(y0 + r > 0 ? y0 + r : 0, G.H - 1), gx = imin(x0 + c > 0 ? x0 + c : 0, G.W - 1);
+    Ip[threadIdx.x] = image[(size_t)gy * G.W + gx];
+  }
+  Row<VPL> LF[kT], LI[kT];
+  if (grp == 0) {
+    const PhaseGeom g0 = tile_geom<0>(w, tw, th), g2 = tile_geom<2>(w, tw, th);
+    Entries<VPL> E0, E2;
+    load_entries<VPL, 0>(E0, g0, ws, G, b, x0, y0, d0);
+    load_entries<VPL, 2>(E2, g2, ws, G, b, x0, y0, d0);
+    if (lr < th) {
+#pragma unroll
+      for (int c = 0; c < HC; ++c) store_row<VPL, true>(Ct + (size_t)(lr * kT + lc + c) * D, 0, D, d0, crow[c]);
+    }
+    STM_STAMP(1);
+    lds_barrier();
+    STM_STAMP(2);
+    Slots<0> s0;
+    s0.init(g0);
+    tile_chains<VPL, 0>(s0, E0, Ct, Ip, P.p1, P.p2, X, lane, LF, LI);
+    STM_STAMP(3);
+    tile_add<VPL, 0, FINAL>(g0, s0, LF, LI, St, P, x0, y0, out, disp, lane);
+    lds_barrier();  // B1
+    STM_STAMP(4);
+    Slots<2> s2;
+    s2.init(g2);
+    tile_chains<VPL, 2>(s2, E2, Ct, Ip, P.p1, P.p2, X, lane, LF, LI);
+    STM_STAMP(5);
+    lds_barrier();  // B2
+    tile_add<VPL, 2, FINAL>(g2, s2, LF, LI, St, P, x0, y0, out, disp, lane);
+    STM_STAMP(6);
+    lds_barrier();  // B3
+    STM_STAMP(7);
+  } else {
+    const PhaseGeom g1 = tile_geom<1>(w, tw, th), g3 = tile_geom<3>(w, tw, th);
+    Entries<VPL> E1, E3;
+    load_entries<VPL, 1>(E1, g1, ws, G, b, x0, y0, d0);
+    load_entries<VPL, 3>(E3, g3, ws, G, b, x0, y0, d0);
+    if (lr < th) {
+#pragma unroll
+      for (int c = 0; c < HC; ++c) store_row<VPL, true>(Ct + (size_t)(lr * kT + lc + c) * D, 0, D, d0, crow[c]);
+    }
+    STM_STAMP(1);
+    lds_barrier();
+    STM_STAMP(2);
+    Slots<1> s1;
+    s1.init(g1);
+    tile_chains<VPL, 1>(s1, E1, Ct, Ip, P.p1, P.p2, X, lane, LF, LI);
+    STM_STAMP(3);
+    lds_barrier();  // B1
+    tile_add<VPL, 1, FINAL>(g1, s1, LF, LI, St, P, x0, y0, out, disp, lane);
+    STM_STAMP(4);
+    lds_barrier();  // B2
+    Slots<3> s3;
+    s3.init(g3);
+    tile_chains<VPL, 3>(s3, E3, Ct, Ip, P.p1, P.p2, X, lane, LF, LI);
+    STM_STAMP(5);
+    lds_barrier();  // B3
+    STM_STAMP(6);
+    tile_add<VPL, 3, FINAL>(g3, s3, LF, LI, St, P, x0, y0, out, disp, lane);
+    STM_STAMP(7);
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------
+#ifdef STM_TILE_STAMPS
+unsigned long long *g_tile_stamps = nullptr;
+unsigned long long *g_sweep_stamps = nullptr;
+#endif
+int sweep_cw(int VPL) { return 8 / VPL; }  // columns per wave: 24 state registers
+
+int device_cus() {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  return n;
+}
+
+struct TiledPlan {
+  TiledGeom G;
+  long long status_off;
+  size_t total_floats;
+  size_t zero_bytes;  // status word + mailboxes, cleared at the start of every call
+  int group;          // images per sweep launch
+};
+
+bool make_plan(int H, int W, int D, int batch, TiledPlan &plan) {
+  const int VPL = D / 64;
+  const int cus = device_cus();
+  if (cus <= 0) return false;
+  const int strip_cols = kSweepWaves * sweep_cw(VPL);
+  const int strips = (W + strip_cols - 1) / strip_cols;
+  if (strips > cus) return false;
+  TiledGeom &G = plan.G;
+  G.H = H; G.W = W; G.D = D;
+  G.nTR = (H + kT - 1) / kT;
+  G.nTC = (W + kT - 1) / kT;
+  G.strips = strips;
+  G.batch = batch;
+  plan.group = cus / strips;
+  if (plan.group > batch) plan.group = batch;
+  long long off = 0;
+  plan.status_off = off;
+  off += 64;  // 256 bytes: status word, padding to keep what follows 16-byte aligned
+  G.mbox_off = off;
+  off += 2ll * batch * strips * 2 * kMboxSlots * D * 2;  // granules are two floats wide
+  plan.zero_bytes = (size_t)off * sizeof(float);
+  // Buffer descriptors address one image's cost volume / border-state block with 32-bit
+  // byte offsets.
+  if ((long long)H * W * D * 4 >= (1ll << 32) || 6ll * G.nTR * W * D * 4 >= (1ll << 32) ||
+      6ll * G.nTC * H * D * 4 >= (1ll << 32))
+    return false;
+  G.rowb_off = off;
+  G.rowb_img = 6ll * G.nTR * W * D;
+  off += G.rowb_img * batch;
+  G.colb_off = off;
+  G.colb_img = 6ll * G.nTC * H * D;
+  off += G.colb_img * batch;
+  plan.total_floats = (size_t)off;
+  return true;
+}
+
+template <int VPL>
+int run_tiled(const float *cost, const float *left, float *out, int32_t *disp, const TiledPlan &plan,
+              float p1, float p2, int dlim, int true_paths, float *ws, int batch, hipStream_t s,
+              int final_mode) {
+  const TiledGeom &G = plan.G;
+  if (hipMemsetAsync(ws, 0, plan.zero_bytes, s) != hipSuccess)
+    return fail(STM_EHIP, "stm_sgm_f32 (tiled): hipMemsetAsync failed");
+  {
+    HwalkArgs A;
+    A.G = G; A.p1 = p1; A.p2 = p2; A.dlim = dlim;
+    const long waves = 2l * G.H * batch;
+    hipLaunchKernelGGL((sgm_hwalk_kernel<VPL>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s,
+                       cost, left, ws, A);
+    int rc = check_launch("stm_sgm_f32 (tiled: horizontal walks)");
+    if (rc != STM_OK) return rc;
+  }
+  for (int up = 0; up < 2; ++up) {
+    for (int b0 = 0; b0 < batch; b0 += plan.group) {
+      SweepArgs A;
+      A.G = G; A.p1 = p1; A.p2 = p2; A.dlim = dlim; A.b0 = b0; A.status_off = plan.status_off;
+#ifdef STM_TILE_STAMPS
+      A.stamps = g_sweep_stamps;
+#endif
+      const int n = batch - b0 < plan.group ? batch - b0 : plan.group;
+      const dim3 grid(G.strips, n), block(kSweepWaves * 64);
+      constexpr int CW = 8 / VPL;  // = sweep_cw(VPL)
+      if (up) hipLaunchKernelGGL((sgm_sweep_kernel<VPL, CW, true>), grid, block, 0, s, cost, left, ws, A);
+      else hipLaunchKernelGGL((sgm_sweep_kernel<VPL, CW, false>), grid, block, 0, s, cost, left, ws, A);
+      int rc = check_launch("stm_sgm_f32 (tiled: row sweep)");
+      if (rc != STM_OK) return rc;
+    }
+  }
+  {
+    TileArgs A;
+    A.G = G; A.p1 = p1; A.p2 = p2; A.dlim = dlim; A.true_paths = true_paths;
+#ifdef STM_TILE_STAMPS
+    A.stamps = g_tile_stamps;
+#endif
+    const dim3 grid((unsigned)(G.nTR * G.nTC), batch), block(2 * kT * 64);
+    if (final_mode == 0)
+      hipLaunchKernelGGL((sgm_tile_kernel<VPL, 0>), grid, block, 0, s, cost, left, out, disp, ws, A);
+    else if (final_mode == 1)
+      hipLaunchKernelGGL((sgm_tile_kernel<VPL, 1>), grid, block, 0, s, cost, left, out, disp, ws, A);
+    else
+      hipLaunchKernelGGL((sgm_tile_kernel<VPL, 2>), grid, block, 0, s, cost, left, out, disp, ws, A);
+    return check_launch("stm_sgm_f32 (tiled: tiles)");
+  }
+}
+
+bool shape_ok(int H, int W, int D, int batch, int flags) {
+  if (flags & (STM_SGM_ACCUMULATE | STM_SGM_SINGLE_PASSES | STM_SGM_EXACT_NONFINITE | STM_SGM_PAIRED))
+    return false;
+  if (D != 64 && D != 128 && D != 256) return false;
+  if (H < 1 || W < 1 || batch < 1 || batch > 65535) return false;
+  if ((long long)((H + kT - 1) / kT) * ((W + kT - 1) / kT) > 0x7fffffffll) return false;
+  return true;
+}
+
+}  // namespace
+
+bool sgm_tiled_selected(int H, int W, int D, int batch, int flags) {
+  if (!shape_ok(H, W, D, batch, flags)) return false;
+  TiledPlan plan;
+  if (!make_plan(H, W, D, batch, plan)) return false;
+  if (flags & STM_SGM_TILED) return true;
+  // The sweeps take a fixed time per image row whatever the number of columns in flight, so
+  // small jobs stay with the paired form: at least half of the chip's columns must be busy.
+  const int cus = device_cus();
+  const int strip_cols = kSweepWaves * sweep_cw(D / 64);
+  return (long long)batch * W * 2 >= (long long)cus * strip_cols && H >= 64;
+}
+
+size_t sgm_tiled_workspace_bytes(int H, int W, int D, int batch, int flags) {
+  if (!sgm_tiled_selected(H, W, D, batch, flags)) return 0;
+  TiledPlan plan;
+  make_plan(H, W, D, batch, plan);
+  return plan.total_floats * sizeof(float);
+}
+
+int sgm_run_tiled(const float *cost, const float *left, float *out, int32_t *disp, int H, int W,
+                  int D, float penalty1, float penalty2, int flags, void *workspace,
+                  size_t workspace_bytes, int batch, hipStream_t stream, int final_mode) {
+  TiledPlan plan;
+  STM_REQUIRE(shape_ok(H, W, D, batch, flags) && make_plan(H, W, D, batch, plan), STM_EUNSUPPORTED,
+              "stm_sgm_f32: the tiled form does not cover this call");
+  const size_t need = plan.total_floats * sizeof(float);
+  STM_REQUIRE(workspace && workspace_bytes >= need, STM_EWORKSPACE,
+              "stm_sgm_f32: needs a workspace of %zu bytes (stm_sgm_workspace_bytes)", need);
+  STM_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(cost) & 15) == 0 &&
+                  (final_mode == 2 || (reinterpret_cast<uintptr_t>(out) & 15) == 0),
+              STM_EINVAL, "stm_sgm_f32: the tiled form needs 16-byte aligned volumes and workspace");
+  const int dlim = (flags & STM_SGM_FULL_MIN) ? D : D - 1;
+  const int true_paths = (flags & STM_SGM_TRUE_PATHS) ? 1 : 0;
+  float *ws = static_cast<float *>(workspace);
+  switch (D / 64) {
+    case 1: return run_tiled<1>(cost, left, out, disp, plan, penalty1, penalty2, dlim, true_paths, ws, batch, stream, final_mode);
+    case 2: return run_tiled<2>(cost, left, out, disp, plan, penalty1, penalty2, dlim, true_paths, ws, batch, stream, final_mode);
+    default: return run_tiled<4>(cost, left, out, disp, plan, penalty1, penalty2, dlim, true_paths, ws, batch, stream, final_mode);
+  }
+}
+
+}  // namespace stm
+
+#ifdef STM_TILE_STAMPS
+extern "C" void stm_debug_set_tile_stamps(void *p) {
+  stm::g_tile_stamps = static_cast<unsigned long long *>(p);
+}
+extern "C" void stm_debug_set_sweep_stamps(void *p) {
+  stm::g_sweep_stamps = static_cast<unsigned long long *>(p);
+}
+#endif

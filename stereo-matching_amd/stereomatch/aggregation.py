@@ -30,7 +30,7 @@ class Semiglobal:
 
     def __init__(self, penalty1: float = 0.1, penalty2: float = 0.2, single_passes: bool = False,
                  paths: str = "reference", full_min: bool = False,
-                 exact_nonfinite: bool = False):
+                 exact_nonfinite: bool = False, form: str = "auto"):
         if paths not in ("reference", "hirschmuller"):
             raise ValueError("Semiglobal paths must be 'reference' or 'hirschmuller'")
         self.penalty1 = penalty1
@@ -42,6 +42,12 @@ class Semiglobal:
         self.paths = paths
         self.full_min = full_min
         self.exact_nonfinite = exact_nonfinite
+        # "auto": the library picks per call between its paired form (a wave per path) and its
+        # tiled form (row sweeps + 8x8 tiles; large batches of D = 64/128/256 volumes);
+        # "paired" / "tiled" force one (tiled only where it covers the call).  Same bits.
+        if form not in _native.STM_SGM_FORMS:
+            raise ValueError("Semiglobal form must be one of %s" % sorted(_native.STM_SGM_FORMS))
+        self.form = form
         # False (default): a direction and its inverse share one pass over the sum (less HBM
         # traffic, larger workspace); True: eight separate passes.  Same bits either way.
         self.single_passes = single_passes
@@ -88,6 +94,7 @@ class Semiglobal:
             flags |= _native.STM_SGM_FULL_MIN
         if self.exact_nonfinite:
             flags |= _native.STM_SGM_EXACT_NONFINITE
+        flags |= _native.STM_SGM_FORMS[self.form]
         if fused:
             disparity_img = output_tensor(cost_volume.shape[:-1], torch.int32, device,
                                           reuse=disparity_img)
@@ -111,3 +118,12 @@ class Semiglobal:
                     max_disparity, float(self.penalty1), float(self.penalty2), flags, ws_ptr,
                     ws_bytes, batch, _native.stream_ptr(device)))
         return sga_volume, disparity_img
+
+    def status(self) -> int:
+        """Status word of the last call's workspace (synchronises the device): 0 = ok; bit 0 =
+        a bounded wait inside the tiled form's row sweeps expired and that call's results are
+        invalid (include/stereomatch_hip.h, "Workspace header")."""
+        if self._workspace is None or self._workspace.numel() < 4:
+            return 0
+        torch.cuda.synchronize(self._workspace.device)
+        return int(self._workspace[:4].view(torch.int32).item())

@@ -1,0 +1,94 @@
+"""The tiled form of the semiglobal aggregation (row sweeps + 8x8 tiles, stm_sgm_tiled.hip)
+against the CPU oracle and against the paired form, bit for bit, through the C ABI.
+
+Shapes cover: images narrower / wider than one column strip (hand-offs between workgroups
+through global mailboxes), widths and heights that are not multiples of the tile or of a
+wave's column count, wide and tall images (the reference's re-walked and skipped inverse
+diagonals), every supported disparity count, batches that need more than one
+sweep launch, the corrected-algorithm options and the fused winner-takes-all."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_parity import _gpu, _random_volume, assert_same_bits
+
+pytestmark = pytest.mark.gpu
+
+TILED_CASES = [
+    (20, 22, 64), (11, 37, 64), (37, 11, 64), (13, 30, 128), (30, 13, 128), (9, 21, 256),
+    (2, 2, 64), (1, 9, 64), (9, 1, 64), (8, 8, 128), (16, 16, 256), (17, 15, 64),
+    (70, 200, 64), (200, 70, 64), (40, 90, 128), (90, 40, 128), (35, 50, 256), (50, 35, 256),
+    (100, 101, 64), (101, 100, 64), (102, 100, 64), (33, 129, 128), (24, 65, 256),
+    (31, 130, 256), (64, 257, 64),
+]
+
+
+def _tiled(**kw):
+    import stereomatch
+    return stereomatch.aggregation.Semiglobal(form="tiled", **kw)
+
+
+@pytest.mark.parametrize("H,W,D", TILED_CASES)
+@pytest.mark.parametrize("kind", ["float", "last"])
+def test_tiled_sgm_matches_oracle(device, oracle, H, W, D, kind):
+    rng = np.random.default_rng(13 * H + 7 * W + D)
+    C = _random_volume(rng, H, W, D, kind)
+    image = rng.integers(0, 5, size=(H, W)).astype(np.float32)
+    want = oracle.sgm(C, image, 0.5, 3.0)
+    sgm = _tiled(penalty1=0.5, penalty2=3.0)
+    got = sgm(_gpu(C, device), _gpu(image, device))
+    assert sgm.status() == 0
+    assert_same_bits(got.cpu().numpy(), want, "tiled sgm " + kind)
+    _, disp = sgm.aggregate_and_reduce(_gpu(C, device), _gpu(image, device))
+    assert sgm.status() == 0
+    assert_same_bits(disp.cpu().numpy(), oracle.wta(want), "tiled fused wta")
+    vol, disp2 = sgm.aggregate_and_reduce(_gpu(C, device), _gpu(image, device), keep_sum=True)
+    assert_same_bits(vol.cpu().numpy(), want, "tiled keep_sum volume")
+    assert_same_bits(disp2.cpu().numpy(), oracle.wta(want), "tiled keep_sum disparity")
+
+
+@pytest.mark.parametrize("H,W,D", [(24, 40, 64), (40, 24, 64), (33, 70, 128), (70, 33, 256)])
+@pytest.mark.parametrize("paths", ["reference", "hirschmuller"])
+@pytest.mark.parametrize("full_min", [False, True])
+def test_tiled_sgm_corrected_modes(device, oracle, H, W, D, paths, full_min):
+    rng = np.random.default_rng(H + W + D)
+    C = _random_volume(rng, H, W, D, "ties")
+    image = rng.integers(0, 4, size=(H, W)).astype(np.float32)
+    want = oracle.sgm(C, image, 0.1, 0.2, full_min=full_min, true_paths=(paths == "hirschmuller"))
+    sgm = _tiled(paths=paths, full_min=full_min)
+    got = sgm(_gpu(C, device), _gpu(image, device))
+    assert sgm.status() == 0
+    assert_same_bits(got.cpu().numpy(), want, "tiled sgm %s full_min=%s" % (paths, full_min))
+
+
+@pytest.mark.parametrize("H,W,D,B", [(14, 31, 64, 3), (31, 14, 64, 3), (40, 300, 64, 70), (20, 500, 256, 20)])
+def test_tiled_sgm_batches(device, oracle, H, W, D, B):
+    """Batches: per-image mailboxes and border states; the last two need several sweep
+    launches (more column strips than the chip has CUs)."""
+    import stereomatch
+    rng = np.random.default_rng(B + H)
+    C = np.stack([_random_volume(rng, H, W, D, "float") for _ in range(B)])
+    image = rng.integers(0, 5, size=(B, H, W)).astype(np.float32)
+    Cg, Ig = _gpu(C, device), _gpu(image, device)
+    sgm = _tiled()
+    S = sgm(Cg, Ig)
+    assert sgm.status() == 0
+    ref = stereomatch.aggregation.Semiglobal(form="paired")(Cg, Ig)
+    assert torch.equal(S.view(torch.int32), ref.view(torch.int32)), "tiled == paired on the batch"
+    for b in range(0, B, max(1, B // 4)):
+        assert_same_bits(S[b].cpu().numpy(), oracle.sgm(C[b], image[b]), "batched tiled sgm %d" % b)
+    _, disp = sgm.aggregate_and_reduce(Cg, Ig)
+    wta = stereomatch.disparity_reduce.WinnerTakesAll()
+    assert torch.equal(disp, wta(ref))
+
+
+def test_tiled_form_is_refused_where_it_does_not_apply(device):
+    """form="tiled" on a shape the tiled form does not cover silently takes the paired form
+    (same results); the flag only ever changes speed."""
+    import stereomatch
+    rng = np.random.default_rng(3)
+    C = _random_volume(rng, 12, 20, 48, "float")
+    image = rng.integers(0, 5, size=(12, 20)).astype(np.float32)
+    a = stereomatch.aggregation.Semiglobal(form="tiled")(_gpu(C, device), _gpu(image, device))
+    b = stereomatch.aggregation.Semiglobal(form="paired")(_gpu(C, device), _gpu(image, device))
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
