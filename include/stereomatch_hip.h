@@ -141,9 +141,9 @@ int stm_birchfield_ex_f32(const float *left, const float *right, float *cost,
 #define STM_SGM_EXACT_NONFINITE 32
 /* Form selection.  By default the library picks per call between the paired form (a wave
  * per path; any shape) and the tiled form (row sweeps + 8x8-pixel tiles: the cost volume is
- * read five times, the sum never travels; D = 64, 128 or 256, no ACCUMULATE /
- * SINGLE_PASSES / EXACT_NONFINITE, and enough columns in the batch to fill the chip).  Same
- * results bit for bit.
+ * read five times, the sum never travels: 32-36 instead of 56-60 bytes per element; covers
+ * D = 64, 128 or 256 without ACCUMULATE / SINGLE_PASSES / EXACT_NONFINITE, chosen by default
+ * for D = 256 with enough columns in the batch to fill the chip).  Same results bit for bit.
  *   STM_SGM_PAIRED  never use the tiled form.
  *   STM_SGM_TILED   use the tiled form whenever it covers the call, whatever the batch size.
  * Both flags must be passed identically to stm_sgm_workspace_bytes().
@@ -161,6 +161,9 @@ size_t stm_sgm_workspace_bytes(int H, int W, int D, int batch, int flags);
 /* Byte offset and meaning of the status word inside a workspace: *(uint32_t*)workspace after
  * the stream has been synchronised; 0 = ok.  Returns the word's value given a HOST copy of
  * the workspace's first 4 bytes (a helper for bindings that cannot cast). */
+/* 1 when stm_sgm_f32 / stm_sgm_wta_f32 will use the tiled form for this call on the current
+ * device (and the workspace therefore starts with the status word), else 0. */
+int stm_sgm_uses_tiles(int H, int W, int D, int batch, int flags);
 #define STM_SGM_STATUS_TIMEOUT 1u
 unsigned stm_sgm_status(const void *host_copy_of_first_word);
 int stm_sgm_f32(const float *cost, const float *left, float *out, int H, int W,

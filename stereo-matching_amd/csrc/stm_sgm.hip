@@ -755,6 +755,10 @@ extern "C" size_t stm_sgm_workspace_bytes(int H, int W, int D, int batch, int fl
   return sgm_plan(H, W, D, batch, !(flags & STM_SGM_SINGLE_PASSES), (flags & STM_SGM_TRUE_PATHS) != 0).total_floats * sizeof(float);
 }
 
+extern "C" int stm_sgm_uses_tiles(int H, int W, int D, int batch, int flags) {
+  return stm::sgm_tiled_selected(H, W, D, batch, flags) ? 1 : 0;
+}
+
 extern "C" unsigned stm_sgm_status(const void *host_copy_of_first_word) {
   return host_copy_of_first_word ? *static_cast<const unsigned *>(host_copy_of_first_word) : 0u;
 }

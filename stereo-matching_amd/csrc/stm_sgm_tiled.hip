@@ -522,18 +522,35 @@ __device__ __forceinline__ PhaseGeom tile_geom(int w, int tw, int th) {
   return g;
 }
 
+// An image's two blocks of border states; offsets inside a block fit 32 bits (make_plan).
+struct BorderBase {
+  const float *rowb, *colb;
+};
+__device__ __forceinline__ BorderBase border_base(float *ws, const TiledGeom &G, int b) {
+  BorderBase B;
+  B.rowb = ws + G.rowb_off + (long long)b * G.rowb_img;
+  B.colb = ws + G.colb_off + (long long)b * G.colb_img;
+  return B;
+}
+__device__ __forceinline__ const float *rowb_at(const BorderBase &B, const TiledGeom &G, int k, int t, int x) {
+  return B.rowb + (unsigned)(((k * G.nTR + t) * G.W + x) * G.D);
+}
+__device__ __forceinline__ const float *colb_at(const BorderBase &B, const TiledGeom &G, int k, int tc, int y) {
+  return B.colb + (unsigned)(((k * G.nTC + tc) * G.H + y) * G.D);
+}
+
 // State of direction `dir` after pixel (gx, gy), which lies on one of the stored lines.
-__device__ __forceinline__ const float *border_ptr(float *ws, const TiledGeom &G, int b, int dir,
-                                                   int gx, int gy) {
+__device__ __forceinline__ const float *border_ptr(const BorderBase &B, const TiledGeom &G, int dir, int gx,
+                                                   int gy) {
   switch (dir) {
-    case 0: return colb_ptr(ws, G, b, 0, gx >> 3, gy);
-    case 1: return colb_ptr(ws, G, b, 3, gx >> 3, gy);
-    case 2: return rowb_ptr(ws, G, b, 0, gy >> 3, gx);
-    case 3: return rowb_ptr(ws, G, b, 3, gy >> 3, gx);
-    case 4: return (gy & 7) == 7 ? rowb_ptr(ws, G, b, 1, gy >> 3, gx) : colb_ptr(ws, G, b, 1, gx >> 3, gy);
-    case 5: return (gy & 7) == 0 ? rowb_ptr(ws, G, b, 5, gy >> 3, gx) : colb_ptr(ws, G, b, 5, gx >> 3, gy);
-    case 6: return (gy & 7) == 7 ? rowb_ptr(ws, G, b, 2, gy >> 3, gx) : colb_ptr(ws, G, b, 4, gx >> 3, gy);
-    default: return (gy & 7) == 0 ? rowb_ptr(ws, G, b, 4, gy >> 3, gx) : colb_ptr(ws, G, b, 2, gx >> 3, gy);
+    case 0: return colb_at(B, G, 0, gx >> 3, gy);
+    case 1: return colb_at(B, G, 3, gx >> 3, gy);
+    case 2: return rowb_at(B, G, 0, gy >> 3, gx);
+    case 3: return rowb_at(B, G, 3, gy >> 3, gx);
+    case 4: return (gy & 7) == 7 ? rowb_at(B, G, 1, gy >> 3, gx) : colb_at(B, G, 1, gx >> 3, gy);
+    case 5: return (gy & 7) == 0 ? rowb_at(B, G, 5, gy >> 3, gx) : colb_at(B, G, 5, gx >> 3, gy);
+    case 6: return (gy & 7) == 7 ? rowb_at(B, G, 2, gy >> 3, gx) : colb_at(B, G, 4, gx >> 3, gy);
+    default: return (gy & 7) == 0 ? rowb_at(B, G, 4, gy >> 3, gx) : colb_at(B, G, 2, gx >> 3, gy);
   }
 }
 
@@ -543,39 +560,38 @@ struct PhaseDir {
   static constexpr int dy = PHASE == 0 ? 0 : 1;
 };
 
-// The four entry states of a wave's phase: [0] F of segment a, [1] I of a, [2] F of b, [3] I
-// of b.  Bit i of `start` set: the path begins at that pixel (L = C), nothing is loaded.
-template <int VPL>
+// The entry states of a wave's phase: [0] F of segment a, [1] I of a and, for the diagonal
+// pairs, [2] F of b, [3] I of b.  Bit i of `start` set: the path begins at that pixel (L = C),
+// nothing is loaded.
+template <int VPL, int PHASE>
 struct Entries {
-  Row<VPL> e[4];
+  static constexpr int N = PHASE >= 2 ? 4 : 2;
+  Row<VPL> e[N];
   unsigned start;
 };
 
 template <int VPL, int PHASE>
-__device__ __forceinline__ void load_entries(Entries<VPL> &E, const PhaseGeom &g, float *ws,
-                                             const TiledGeom &G, int b, int x0, int y0, int d0) {
+__device__ __forceinline__ void load_entries(Entries<VPL, PHASE> &E, const PhaseGeom &g,
+                                             const BorderBase &B, const TiledGeom &G, int x0, int y0,
+                                             int d0) {
   constexpr int dx = PhaseDir<PHASE>::dx, dy = PhaseDir<PHASE>::dy;
   constexpr int D = 64 * VPL;
   E.start = 0;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < Entries<VPL, PHASE>::N / 2; ++i) {
     const Seg &s = i == 0 ? g.a : g.b;
     const int fx = x0 + s.ex - dx, fy = y0 + s.ey - dy;
     const int ix = x0 + s.ex + s.n * dx, iy = y0 + s.ey + s.n * dy;
     const bool fin = s.n > 0 && fx >= 0 && fx < G.W && fy >= 0 && fy < G.H;
     const bool iin = s.n > 0 && ix >= 0 && ix < G.W && iy >= 0 && iy < G.H;
-    if (fin) E.e[2 * i] = load_row<VPL, true>(border_ptr(ws, G, b, 2 * PHASE, fx, fy), 0, D, d0);
-    else E.start |= 1u << (2 * i);
-    if (iin) E.e[2 * i + 1] = load_row<VPL, true>(border_ptr(ws, G, b, 2 * PHASE + 1, ix, iy), 0, D, d0);
-    else E.start |= 2u << (2 * i);
-    if (!fin) {
-#pragma unroll
-      for (int j = 0; j < VPL; ++j) E.e[2 * i].v[j] = 0.0f;
-    }
-    if (!iin) {
-#pragma unroll
-      for (int j = 0; j < VPL; ++j) E.e[2 * i + 1].v[j] = 0.0f;
-    }
+    // A segment that does not exist or begins at the image border reads a valid dummy address:
+    // the load stays unconditional (one definition of the registers), its value is not used.
+    const float *fp = fin ? border_ptr(B, G, 2 * PHASE, fx, fy) : B.rowb;
+    const float *ip = iin ? border_ptr(B, G, 2 * PHASE + 1, ix, iy) : B.rowb;
+    E.e[2 * i] = load_row<VPL, true>(fp, 0, D, d0);
+    E.e[2 * i + 1] = load_row<VPL, true>(ip, 0, D, d0);
+    if (!fin && s.n > 0) E.start |= 1u << (2 * i);
+    if (!iin && s.n > 0) E.start |= 2u << (2 * i);
   }
 }
 
@@ -636,7 +652,7 @@ struct Slots {
 
 // Both chains of a phase: LF[s] / LI[s] = L of the forward / inverse direction at slot s.
 template <int VPL, int PHASE>
-__device__ __forceinline__ void tile_chains(const Slots<PHASE> &sl, const Entries<VPL> &E, const float *Ct,
+__device__ __forceinline__ void tile_chains(const Slots<PHASE> &sl, const Entries<VPL, PHASE> &E, const float *Ct,
                                             const float *Ip, float p1, float p2, StepCtx &X, int lane,
                                             Row<VPL> (&LF)[kT], Row<VPL> (&LI)[kT]) {
   constexpr int dx = PhaseDir<PHASE>::dx, dy = PhaseDir<PHASE>::dy;
@@ -667,7 +683,7 @@ __device__ __forceinline__ void tile_chains(const Slots<PHASE> &sl, const Entrie
         if (s == 0) {
           start = (E.start & 1u) != 0;
         } else if (PHASE >= 2 && s == nA) {  // the second diagonal begins
-          pf = E.e[2];
+          if constexpr (PHASE >= 2) pf = E.e[2];
           start = (E.start & 4u) != 0;
         }
         Row<VPL> cur = sgm_step<VPL, true>(pf, c, read_lane(pen, s), X);
@@ -683,7 +699,9 @@ __device__ __forceinline__ void tile_chains(const Slots<PHASE> &sl, const Entrie
         bool start = false;
         if (s == nT - 1) {
           const bool seg_b = PHASE >= 2 && s >= nA;
-          if (seg_b) pi = E.e[3];
+          if constexpr (PHASE >= 2) {
+            if (seg_b) pi = E.e[3];
+          }
           start = (E.start & (seg_b ? 8u : 2u)) != 0;
         } else if (PHASE >= 2 && s == nA - 1) {  // back in the first diagonal
           pi = E.e[1];
@@ -764,6 +782,119 @@ __device__ __forceinline__ void tile_add(const PhaseGeom &g, const Slots<PHASE> 
   }
 }
 
+// The same two chains for the common case -- a full 8 x 8 tile, no path beginning inside it
+// (E.start == 0) -- without the per-slot validity and image-border logic: a wave issues in
+// order and the tile kernel is bound by instruction issue, so what the generic form spends on
+// selects, branches and register copies per slot is tile time.  All eight slots exist; on the
+// diagonal pairs the second segment begins at slot nA (nA = 8: there is none).
+template <int VPL, int PHASE>
+__device__ __forceinline__ void tile_chains_fast(const Slots<PHASE> &sl, const Entries<VPL, PHASE> &E,
+                                                 const float *Ct, const float *Ip, float p1, float p2,
+                                                 StepCtx &X, int lane, Row<VPL> (&LF)[kT], Row<VPL> (&LI)[kT]) {
+  constexpr int dx = PhaseDir<PHASE>::dx, dy = PhaseDir<PHASE>::dy;
+  const int d0 = lane * VPL;
+  const int nA = sl.nA;
+  float pen;
+  {
+    const int s = lane & 7;
+    const bool inv = (lane >> 3) & 1;
+    int pix = sl.pix[0];
+#pragma unroll
+    for (int k = 1; k < kT; ++k) pix = s == k ? sl.pix[k] : pix;
+    const int px = pix & (kT - 1), py = pix >> 3;
+    const int qx = px + (inv ? dx : -dx), qy = py + (inv ? dy : -dy);
+    pen = sgm_penalty(Ip[(py + 1) * (kT + 2) + px + 1], Ip[(qy + 1) * (kT + 2) + qx + 1], p1, p2);
+  }
+  Row<VPL> pf = E.e[0];
+#pragma unroll
+  for (int s = 0; s < kT; ++s) {
+    if constexpr (PHASE >= 2) {
+      if (s > 0 && s == nA) pf = E.e[2];
+    }
+    pf = sgm_step<VPL, true>(pf, lds_row<VPL>(Ct, sl.pix[s], d0), read_lane(pen, s), X);
+    LF[s] = pf;
+  }
+  Row<VPL> pi;
+  if constexpr (PHASE >= 2) pi = nA < kT ? E.e[3] : E.e[1];
+  else pi = E.e[1];
+#pragma unroll
+  for (int s = kT - 1; s >= 0; --s) {
+    if constexpr (PHASE >= 2) {
+      if (s < kT - 1 && s == nA - 1) pi = E.e[1];
+    }
+    pi = sgm_step<VPL, true>(pi, lds_row<VPL>(Ct, sl.pix[s], d0), read_lane(pen, 8 + s), X);
+    LI[s] = pi;
+  }
+}
+
+// ... and the sum update when every direction counts once: S = (S + F) + I.
+template <int VPL, int PHASE, int FINAL>
+__device__ __forceinline__ void tile_add_fast(const Slots<PHASE> &sl, const Row<VPL> (&LF)[kT],
+                                              const Row<VPL> (&LI)[kT], float *St, int W, int x0, int y0,
+                                              float *__restrict__ out, int32_t *__restrict__ disp, int lane) {
+  constexpr int D = 64 * VPL;
+  const int d0 = lane * VPL;
+#pragma unroll
+  for (int s = 0; s < kT; ++s) {
+    const int pix = sl.pix[s];
+    Row<VPL> acc;
+    if (PHASE == 0) {
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) acc.v[j] = 0.0f;
+    } else {
+      acc = lds_row<VPL>(St, pix, d0);
+    }
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) acc.v[j] = (acc.v[j] + LF[s].v[j]) + LI[s].v[j];
+    if (PHASE < 3) {
+      store_row<VPL, true>(St + (size_t)pix * D, 0, D, d0, acc);
+    } else {
+      const size_t q = (size_t)(y0 + (pix >> 3)) * W + (x0 + (pix & (kT - 1)));
+      if (FINAL != 2) store_row<VPL, true>(out, q, D, d0, acc);
+      if (FINAL != 0) {
+        float best = __builtin_inff();
+        int idx = d0;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j)
+          if (acc.v[j] < best) { best = acc.v[j]; idx = d0 + j; }
+        const float m = wave_min_f32(best);
+        const int win = __builtin_amdgcn_readlane(idx, __builtin_ctzll(__ballot(best == m)));
+        const float first = read_lane(acc.v[0], 0);
+        if (lane == 0) disp[q] = (first != first) ? 0 : win;
+      }
+    }
+  }
+}
+
+// One pair of a tile for one wave: chains, then (after `between`, the barrier the pair's
+// update has to wait for, if any) the update of the sum tile.  Picks the fast forms when the
+// tile is full, no path begins in it and the pair counts once everywhere.
+template <int VPL, int PHASE, int FINAL, typename Between>
+__device__ __forceinline__ void tile_pair(const PhaseGeom &g, const Entries<VPL, PHASE> &E, bool full,
+                                          const float *Ct, float *St, const float *Ip, const TileArgs &P,
+                                          int x0, int y0, float *__restrict__ out,
+                                          int32_t *__restrict__ disp, StepCtx &X, int lane,
+                                          Between between) {
+  Row<VPL> LF[kT], LI[kT];
+  Slots<PHASE> sl;
+  sl.init(g);
+  bool fast = full && E.start == 0;
+  if (PHASE >= 2 && fast) {
+    const Counts ca = seg_counts<PHASE>(g.a, x0, y0, P.G, P.true_paths);
+    const Counts cb = seg_counts<PHASE>(g.b, x0, y0, P.G, P.true_paths);
+    fast = ca.inv == 1 && ca.pre == 0 && cb.inv == 1 && cb.pre == 0;
+  }
+  if (fast) {
+    tile_chains_fast<VPL, PHASE>(sl, E, Ct, Ip, P.p1, P.p2, X, lane, LF, LI);
+    between();
+    tile_add_fast<VPL, PHASE, FINAL>(sl, LF, LI, St, P.G.W, x0, y0, out, disp, lane);
+  } else {
+    tile_chains<VPL, PHASE>(sl, E, Ct, Ip, P.p1, P.p2, X, lane, LF, LI);
+    between();
+    tile_add<VPL, PHASE, FINAL>(g, sl, LF, LI, St, P, x0, y0, out, disp, lane);
+  }
+}
+
 // Sixteen waves per tile in two groups of eight: group 0 handles the direction pairs 0
 // (right/left) and 2 (down-right/up-left), group 1 the pairs 1 (down/up) and 3
 // (down-left/up-right).  The chains of a pair only read the cost tile, so the two groups run
@@ -771,6 +902,36 @@ __device__ __forceinline__ void tile_add(const PhaseGeom &g, const Slots<PHASE> 
 // in the reference's order:
 //   group 0: chains 0, add 0 | B1 | chains 2        | B2 | add 2    | B3 |
 //   group 1: chains 1        | B1 | add 1           | B2 | chains 3 | B3 | add 3
+// The tile's cost and sum occupy 128 of the CU's 160 KB of LDS, so one workgroup per CU; it is
+// persistent and walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...  A tile's 160 KB of loads
+// would be exposed once per tile, so they are issued where the issuing group is about to wait
+// anyway and few registers are live (the kernel runs at the 128-register limit of a
+// 1024-thread workgroup: both chains' results of a pair are 64 of them):
+//   group 0, after add 2 (then waits at B3 for group 1's chains 3): the whole cost tile of the
+//            next tile (8 pixels per wave), its intensities and group 0's first border states;
+//   group 1, after chains 3: its first border states of the next tile;
+//   either group, after its first add: the border states of its second pair.
+// Position of a tile, advanced by gridDim.x tiles at a time without divisions.
+struct TileWalk {
+  int b, trow, tcol;     // image, tile row, tile column
+  int drow, dcol;        // gridDim.x = drow * nTC + dcol
+  __device__ __forceinline__ void init(int first, int stride, const TiledGeom &G) {
+    const int per_image = G.nTR * G.nTC;
+    b = first / per_image;
+    const int t = first - b * per_image;
+    trow = t / G.nTC;
+    tcol = t - trow * G.nTC;
+    drow = stride / G.nTC;
+    dcol = stride - drow * G.nTC;
+  }
+  __device__ __forceinline__ void next(const TiledGeom &G) {
+    tcol += dcol;
+    trow += drow;
+    if (tcol >= G.nTC) { tcol -= G.nTC; ++trow; }
+    while (trow >= G.nTR) { trow -= G.nTR; ++b; }
+  }
+};
+
 template <int VPL, int FINAL>
 __global__ __launch_bounds__(2 * kT * 64) void sgm_tile_kernel(const float *__restrict__ cost_all,
                                                                const float *__restrict__ image_all,
@@ -786,93 +947,122 @@ __global__ __launch_bounds__(2 * kT * 64) void sgm_tile_kernel(const float *__re
   const int w16 = wave_uniform((int)(threadIdx.x >> 6));
   const int grp = w16 >> 3, w = w16 & (kT - 1);
   const int d0 = lane * VPL;
-  const int tile = blockIdx.x;
-  const int b = blockIdx.y;
-  const int trow = tile / G.nTC, tcol = tile - trow * G.nTC;
-  const int x0 = tcol * kT, y0 = trow * kT;
-  const int tw = imin(kT, G.W - x0), th = imin(kT, G.H - y0);
   const size_t npix = (size_t)G.H * G.W;
-  const float *cost = cost_all + (size_t)b * npix * D;
-  const float *image = image_all + (size_t)b * npix;
-  float *out = out_all ? out_all + (size_t)b * npix * D : nullptr;
-  int32_t *disp = disp_all ? disp_all + (size_t)b * npix : nullptr;
+  const int ntiles = G.batch * G.nTR * G.nTC;  // < 2^31 (shape_ok)
+  const int stride = (int)gridDim.x;
   StepCtx X;
   X.init(P.p1, d0, P.dlim, lane == 63 && P.dlim < D);
+  TileWalk cur_t, next_t;  // the tile being computed / the one being prefetched
+  cur_t.init((int)blockIdx.x, stride, G);
+  next_t = cur_t;
+  int id = (int)blockIdx.x;
 
-  STM_STAMP(0);
-  // The tile's cost rows: wave w16 brings half of tile row w16 / 2.
-  constexpr int HC = kT / 2;
-  const int lr = w16 >> 1, lc = (w16 & 1) * HC;
-  Row<VPL> crow[HC];
-  if (lr < th) {
-#pragma unroll
-    for (int c = 0; c < HC; ++c)
-      crow[c] = load_row<VPL, true>(cost, (size_t)(y0 + lr) * G.W + x0 + imin(lc + c, tw - 1), D, d0);
-  }
-  // Intensities of the tile and the ring of pixels around it (clamped at the image border;
-  // a clamped sample is only ever used for a step that does not exist).
-  if (threadIdx.x < (kT + 2) * (kT + 2)) {
-    const int r = (int)threadIdx.x / (kT + 2) - 1, c = (int)threadIdx.x % (kT + 2) - 1;
-    const int gy = imin(y0 + r > 0 ? y0 + r : 0, G.H - 1), gx = imin(x0 + c > 0 ? x0 + c : 0, G.W - 1);
-    Ip[threadIdx.x] = image[(size_t)gy * G.W + gx];
-  }
-  Row<VPL> LF[kT], LI[kT];
   if (grp == 0) {
-    const PhaseGeom g0 = tile_geom<0>(w, tw, th), g2 = tile_geom<2>(w, tw, th);
-    Entries<VPL> E0, E2;
-    load_entries<VPL, 0>(E0, g0, ws, G, b, x0, y0, d0);
-    load_entries<VPL, 2>(E2, g2, ws, G, b, x0, y0, d0);
-    if (lr < th) {
+    Row<VPL> cpre[kT];   // next tile: tile row w of the cost tile
+    float ipre = 0.0f;   // next tile: this thread's element of the intensity patch
+    Entries<VPL, 0> E0;  // next tile: border states of pair 0
+    // Every prefetch redefines all of its registers unconditionally (past the last tile it
+    // re-reads that tile, rows and samples outside a partial tile are clamped into it): a
+    // conditional load would keep the previous contents alive around the whole loop.
+    auto prefetch = [&](const TileWalk &t) {
+      const int x0 = t.tcol * kT, y0 = t.trow * kT;
+      const int tw = imin(kT, G.W - x0), th = imin(kT, G.H - y0);
+      const float *cost = cost_all + (size_t)t.b * npix * D;
+      const unsigned rowbase = (unsigned)((y0 + imin(w, th - 1)) * G.W + x0);
 #pragma unroll
-      for (int c = 0; c < HC; ++c) store_row<VPL, true>(Ct + (size_t)(lr * kT + lc + c) * D, 0, D, d0, crow[c]);
+      for (int c = 0; c < kT; ++c)
+        cpre[c] = load_row_at<VPL, true>(cost, (long)((rowbase + (unsigned)imin(c, tw - 1)) * (unsigned)D), D, d0);
+      // Intensities of the tile and the ring of pixels around it (clamped at the image border;
+      // a clamped sample is only ever used for a step that does not exist).
+      {
+        const int e = imin((int)threadIdx.x, (kT + 2) * (kT + 2) - 1);
+        const int r = e / (kT + 2) - 1, c = e % (kT + 2) - 1;
+        const int gy = imin(y0 + r > 0 ? y0 + r : 0, G.H - 1), gx = imin(x0 + c > 0 ? x0 + c : 0, G.W - 1);
+        ipre = image_all[(size_t)t.b * npix + (unsigned)(gy * G.W + gx)];
+      }
+      load_entries<VPL, 0>(E0, tile_geom<0>(w, tw, th), border_base(ws, G, t.b), G, x0, y0, d0);
+    };
+    prefetch(next_t);
+    for (; id < ntiles; id += stride) {
+      const int b = cur_t.b, x0 = cur_t.tcol * kT, y0 = cur_t.trow * kT;
+      const int tw = imin(kT, G.W - x0), th = imin(kT, G.H - y0);
+      const bool full = tw == kT && th == kT;
+      float *out = out_all ? out_all + (size_t)b * npix * D : nullptr;
+      int32_t *disp = disp_all ? disp_all + (size_t)b * npix : nullptr;
+#ifdef STM_TILE_STAMPS
+      const int tile = id < 4096 ? id : 4096;
+#endif
+      STM_STAMP(0);
+      if (w < th) {
+#pragma unroll
+        for (int c = 0; c < kT; ++c) store_row<VPL, true>(Ct + (size_t)(w * kT + c) * D, 0, D, d0, cpre[c]);
+      }
+      if (threadIdx.x < (kT + 2) * (kT + 2)) Ip[threadIdx.x] = ipre;
+      const Entries<VPL, 0> E0now = E0;
+      STM_STAMP(1);
+      lds_barrier();  // B0
+      STM_STAMP(2);
+      tile_pair<VPL, 0, FINAL>(tile_geom<0>(w, tw, th), E0now, full, Ct, St, Ip, P, x0, y0, out, disp, X, lane,
+                               [] {});
+      STM_STAMP(3);
+      const PhaseGeom g2 = tile_geom<2>(w, tw, th);
+      Entries<VPL, 2> E2;
+      load_entries<VPL, 2>(E2, g2, border_base(ws, G, b), G, x0, y0, d0);
+      lds_barrier();  // B1
+      STM_STAMP(4);
+      tile_pair<VPL, 2, FINAL>(g2, E2, full, Ct, St, Ip, P, x0, y0, out, disp, X, lane, [&] {
+        STM_STAMP(5);
+        lds_barrier();  // B2
+      });
+      STM_STAMP(6);
+      if (id + stride < ntiles) next_t.next(G);
+      prefetch(next_t);
+      cur_t = next_t;
+      lds_barrier();  // B3
+      STM_STAMP(7);
     }
-    STM_STAMP(1);
-    lds_barrier();
-    STM_STAMP(2);
-    Slots<0> s0;
-    s0.init(g0);
-    tile_chains<VPL, 0>(s0, E0, Ct, Ip, P.p1, P.p2, X, lane, LF, LI);
-    STM_STAMP(3);
-    tile_add<VPL, 0, FINAL>(g0, s0, LF, LI, St, P, x0, y0, out, disp, lane);
-    lds_barrier();  // B1
-    STM_STAMP(4);
-    Slots<2> s2;
-    s2.init(g2);
-    tile_chains<VPL, 2>(s2, E2, Ct, Ip, P.p1, P.p2, X, lane, LF, LI);
-    STM_STAMP(5);
-    lds_barrier();  // B2
-    tile_add<VPL, 2, FINAL>(g2, s2, LF, LI, St, P, x0, y0, out, disp, lane);
-    STM_STAMP(6);
-    lds_barrier();  // B3
-    STM_STAMP(7);
   } else {
-    const PhaseGeom g1 = tile_geom<1>(w, tw, th), g3 = tile_geom<3>(w, tw, th);
-    Entries<VPL> E1, E3;
-    load_entries<VPL, 1>(E1, g1, ws, G, b, x0, y0, d0);
-    load_entries<VPL, 3>(E3, g3, ws, G, b, x0, y0, d0);
-    if (lr < th) {
-#pragma unroll
-      for (int c = 0; c < HC; ++c) store_row<VPL, true>(Ct + (size_t)(lr * kT + lc + c) * D, 0, D, d0, crow[c]);
+    Entries<VPL, 1> E1;  // next tile: border states of pair 1
+    auto prefetch = [&](const TileWalk &t) {
+      const int x0 = t.tcol * kT, y0 = t.trow * kT;
+      const int tw = imin(kT, G.W - x0), th = imin(kT, G.H - y0);
+      load_entries<VPL, 1>(E1, tile_geom<1>(w, tw, th), border_base(ws, G, t.b), G, x0, y0, d0);
+    };
+    prefetch(next_t);
+    for (; id < ntiles; id += stride) {
+      const int b = cur_t.b, x0 = cur_t.tcol * kT, y0 = cur_t.trow * kT;
+      const int tw = imin(kT, G.W - x0), th = imin(kT, G.H - y0);
+      const bool full = tw == kT && th == kT;
+      float *out = out_all ? out_all + (size_t)b * npix * D : nullptr;
+      int32_t *disp = disp_all ? disp_all + (size_t)b * npix : nullptr;
+#ifdef STM_TILE_STAMPS
+      const int tile = id < 4096 ? id : 4096;
+#endif
+      STM_STAMP(0);
+      const Entries<VPL, 1> E1now = E1;
+      STM_STAMP(1);
+      lds_barrier();  // B0
+      STM_STAMP(2);
+      tile_pair<VPL, 1, FINAL>(tile_geom<1>(w, tw, th), E1now, full, Ct, St, Ip, P, x0, y0, out, disp, X, lane,
+                               [&] {
+                                 STM_STAMP(3);
+                                 lds_barrier();  // B1
+                               });
+      const PhaseGeom g3 = tile_geom<3>(w, tw, th);
+      Entries<VPL, 3> E3;
+      load_entries<VPL, 3>(E3, g3, border_base(ws, G, b), G, x0, y0, d0);
+      STM_STAMP(4);
+      lds_barrier();  // B2
+      if (id + stride < ntiles) next_t.next(G);
+      tile_pair<VPL, 3, FINAL>(g3, E3, full, Ct, St, Ip, P, x0, y0, out, disp, X, lane, [&] {
+        prefetch(next_t);
+        STM_STAMP(5);
+        lds_barrier();  // B3
+        STM_STAMP(6);
+      });
+      cur_t = next_t;
+      STM_STAMP(7);
     }
-    STM_STAMP(1);
-    lds_barrier();
-    STM_STAMP(2);
-    Slots<1> s1;
-    s1.init(g1);
-    tile_chains<VPL, 1>(s1, E1, Ct, Ip, P.p1, P.p2, X, lane, LF, LI);
-    STM_STAMP(3);
-    lds_barrier();  // B1
-    tile_add<VPL, 1, FINAL>(g1, s1, LF, LI, St, P, x0, y0, out, disp, lane);
-    STM_STAMP(4);
-    lds_barrier();  // B2
-    Slots<3> s3;
-    s3.init(g3);
-    tile_chains<VPL, 3>(s3, E3, Ct, Ip, P.p1, P.p2, X, lane, LF, LI);
-    STM_STAMP(5);
-    lds_barrier();  // B3
-    STM_STAMP(6);
-    tile_add<VPL, 3, FINAL>(g3, s3, LF, LI, St, P, x0, y0, out, disp, lane);
-    STM_STAMP(7);
   }
 }
 
@@ -972,7 +1162,11 @@ int run_tiled(const float *cost, const float *left, float *out, int32_t *disp, c
 #ifdef STM_TILE_STAMPS
     A.stamps = g_tile_stamps;
 #endif
-    const dim3 grid((unsigned)(G.nTR * G.nTC), batch), block(2 * kT * 64);
+    // Persistent workgroups, one per CU (the LDS allows no more); tiles are dealt round robin.
+    const long long ntiles = (long long)G.nTR * G.nTC * batch;
+    // (two per CU where the tile's LDS footprint allows it: D <= 128)
+    const long long wgs = (long long)device_cus() * (VPL >= 4 ? 1 : 2);
+    const dim3 grid((unsigned)(ntiles < wgs ? ntiles : wgs)), block(2 * kT * 64);
     if (final_mode == 0)
       hipLaunchKernelGGL((sgm_tile_kernel<VPL, 0>), grid, block, 0, s, cost, left, out, disp, ws, A);
     else if (final_mode == 1)
@@ -988,7 +1182,7 @@ bool shape_ok(int H, int W, int D, int batch, int flags) {
     return false;
   if (D != 64 && D != 128 && D != 256) return false;
   if (H < 1 || W < 1 || batch < 1 || batch > 65535) return false;
-  if ((long long)((H + kT - 1) / kT) * ((W + kT - 1) / kT) > 0x7fffffffll) return false;
+  if ((long long)batch * ((H + kT - 1) / kT) * ((W + kT - 1) / kT) > 0x3fffffffll) return false;
   return true;
 }
 
@@ -999,11 +1193,14 @@ bool sgm_tiled_selected(int H, int W, int D, int batch, int flags) {
   TiledPlan plan;
   if (!make_plan(H, W, D, batch, plan)) return false;
   if (flags & STM_SGM_TILED) return true;
-  // The sweeps take a fixed time per image row whatever the number of columns in flight, so
-  // small jobs stay with the paired form: at least half of the chip's columns must be busy.
+  // Measured on MI355X (tools/sgm_forms.py): the tiled form wins where the volume traffic it
+  // saves outweighs its fixed costs per image row and per tile -- D = 256 with enough columns
+  // in the batch to keep the row sweeps' column strips on most CUs (1080p: from 3 pairs; 4.3
+  // against 5.8 ms per pair at 8-16 pairs, 8.0 against 6.0 ms for a single pair).  At D = 128 the
+  // two forms are level and at D = 64 the paired form is faster, so they stay with it.
   const int cus = device_cus();
   const int strip_cols = kSweepWaves * sweep_cw(D / 64);
-  return (long long)batch * W * 2 >= (long long)cus * strip_cols && H >= 64;
+  return D == 256 && (long long)batch * W * 2 >= (long long)cus * strip_cols && H >= 64;
 }
 
 size_t sgm_tiled_workspace_bytes(int H, int W, int D, int batch, int flags) {

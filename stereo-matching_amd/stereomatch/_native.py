@@ -36,6 +36,7 @@ PROTOTYPES = {
     "stm_birchfield_ex_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "stm_sgm_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "stm_sgm_status": (ctypes.c_uint, [_vp]),
+    "stm_sgm_uses_tiles": (_i, [_i, _i, _i, _i, _i]),
     "stm_sgm_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _sz, _i, _vp]),
     "stm_sgm_wta_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _sz, _i, _vp]),
     "stm_wta_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -52,6 +52,7 @@ class Semiglobal:
         # traffic, larger workspace); True: eight separate passes.  Same bits either way.
         self.single_passes = single_passes
         self._workspace = None
+        self._last_tiled = False
 
     def __call__(self, cost_volume: torch.Tensor, left_image: torch.Tensor,
                  sga_volume: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -101,6 +102,7 @@ class Semiglobal:
             if keep_sum:
                 flags |= _native.STM_SGM_KEEP_SUM
         ws_bytes = lib.stm_sgm_workspace_bytes(height, width, max_disparity, batch, flags)
+        self._last_tiled = bool(lib.stm_sgm_uses_tiles(height, width, max_disparity, batch, flags))
         if ws_bytes and (self._workspace is None or self._workspace.device != device
                          or self._workspace.numel() < ws_bytes):
             self._workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
@@ -123,7 +125,7 @@ class Semiglobal:
         """Status word of the last call's workspace (synchronises the device): 0 = ok; bit 0 =
         a bounded wait inside the tiled form's row sweeps expired and that call's results are
         invalid (include/stereomatch_hip.h, "Workspace header")."""
-        if self._workspace is None or self._workspace.numel() < 4:
-            return 0
+        if not self._last_tiled or self._workspace is None or self._workspace.numel() < 4:
+            return 0  # the paired form has no bounded waits (and no status word)
         torch.cuda.synchronize(self._workspace.device)
         return int(self._workspace[:4].view(torch.int32).item())

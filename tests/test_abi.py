@@ -18,8 +18,8 @@ def declared_symbols():
 def test_header_declares_the_expected_entry_points():
     assert declared_symbols() == sorted([
         "stm_abi_version", "stm_last_error", "stm_ssd_workspace_bytes", "stm_ssd_f32",
-        "stm_birchfield_f32", "stm_birchfield_ex_f32", "stm_sgm_workspace_bytes", "stm_sgm_f32", "stm_sgm_wta_f32", "stm_wta_f32",
-        "stm_dp_f32"])
+        "stm_birchfield_f32", "stm_birchfield_ex_f32", "stm_sgm_workspace_bytes", "stm_sgm_uses_tiles",
+        "stm_sgm_status", "stm_sgm_f32", "stm_sgm_wta_f32", "stm_wta_f32", "stm_dp_f32"])
 
 
 def test_library_exports_every_declared_symbol():
