@@ -180,9 +180,12 @@ def roofline(job, sgm_ms, traffic_and_note=(None, None)):
     traffic, note = traffic_and_note
     algorithmic = 8.0 * job.n_elems * job.batch  # read cost once + write sum once
     achieved = algorithmic / (sgm_ms * 1e-3) / 1e9
+    tiled = bool(getattr(job.sgm, "_last_tiled", False))
+    kernels = ("tiled form: sgm_hwalk_kernel + sgm_sweep_kernel (down, up) + sgm_tile_kernel" if tiled
+               else "paired form: sgm_ckpt_kernel + 4 x sgm_pair_kernel")
     return {"bound": "hbm", "traffic_note": note,
-            "kernel": "semiglobal aggregation with fused WTA: sgm_ckpt_kernel + 4 x sgm_pair_kernel "
-                      "(stm_sgm_wta_f32)",
+            "kernel": "semiglobal aggregation with fused WTA (stm_sgm_wta_f32), " + kernels,
+            "form": "tiled" if tiled else "paired",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes": algorithmic, "ms": round(sgm_ms, 4),
@@ -217,6 +220,11 @@ def load_traffic(name, batch):
     per_pair = doc.get(name + "_per_pair")
     if per_pair is None:
         return None, "profiles/traffic.json has no %s_per_pair" % name
+    if doc.get(name + "_pairs_per_step") not in (None, batch):
+        # the library picks the aggregation's form by batch size: a figure measured at another
+        # batch may belong to other kernels
+        return None, "profiles/traffic.json was measured at %s pairs per step, this run uses %d" % (
+            doc.get(name + "_pairs_per_step"), batch)
     have, want = doc.get("csrc_sha16"), csrc_sha16()
     if have != want:
         return None, "profiles/traffic.json was measured on kernel sources %s, this tree is %s" % (have, want)

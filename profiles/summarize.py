@@ -45,7 +45,7 @@ def load(path):
 
 def main():
     tag, trace_dir, fetch_dir, write_dir = sys.argv[1:5]
-    prefix = "r01"
+    prefix = os.environ.get("STM_PROF_PREFIX", "r01")
     # pairs per step of the two workloads in the profiled bench runs (per-pair figures are stored)
     batches = {"teddy": int(sys.argv[5]) if len(sys.argv) > 5 else 64,
                "1080p": int(sys.argv[6]) if len(sys.argv) > 6 else 4}
@@ -75,9 +75,10 @@ def main():
             f.write("%s,%d,%.1f,%.1f,%.1f\n" % (k[0].replace(",", ";"), k[1], fr, 2 * fr,
                                                  counters["WRITE_SIZE"].get(k, 0.0)))
 
-    # HBM bytes per aggregation: dispatches in order, one group per sgm_ckpt_kernel launch
-    # (ckpt + 4 pair launches + repeat kernels); groups whose last pair kernel is the fused
-    # disparity-only variant (template argument FINAL = 2) are the ones bench.py times.
+    # HBM bytes per aggregation call: dispatches in order; a call begins with sgm_hwalk_kernel
+    # (tiled form: + row sweeps + sgm_tile_kernel) or sgm_ckpt_kernel (paired form: + 4 pair
+    # launches + repeat kernels).  Calls whose last kernel is the fused disparity-only variant
+    # (sgm_tile_kernel<VPL, 2> / sgm_pair_kernel<.., FINAL = 2, ..>) are the ones bench.py times.
     def per_step(vpl):
         out = {}
         for name, d, scale in (("FETCH_SIZE", fetch_dir, 2.0), ("WRITE_SIZE", write_dir, 1.0)):
@@ -87,18 +88,20 @@ def main():
             groups, cur = [], None
             for r in rows:
                 k = short(r["Kernel_Name"])
-                if k.startswith("sgm_ckpt_kernel"):
-                    cur = {"vpl": k, "bytes": 0.0, "fused": False}
+                if k.startswith("sgm_ckpt_kernel") or k.startswith("sgm_hwalk_kernel"):
+                    cur = {"vpl": k, "bytes": 0.0, "fused": False,
+                           "form": "tiled" if k.startswith("sgm_hwalk") else "paired"}
                     groups.append(cur)
                 if cur is None:
                     continue
                 cur["bytes"] += float(r["Counter_Value"]) * 1024.0 * scale
-                # sgm_pair_kernel<VPL, VEC, FIRST, FINAL, NT>: FINAL = 2 is the disparity-only form
-                if k.startswith("sgm_pair_kernel"):
+                if k.startswith("sgm_pair_kernel") or k.startswith("sgm_tile_kernel"):
                     args = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")]
-                    if len(args) >= 4 and args[3] == "2":
+                    final = args[3] if k.startswith("sgm_pair_kernel") and len(args) >= 4 else args[1]
+                    if final == "2":
                         cur["fused"] = True
-            mine = [g for g in groups if g["vpl"].startswith("sgm_ckpt_kernel<%d," % vpl)]
+            mine = [g for g in groups if g["vpl"].split("<")[1].split(",")[0].rstrip(">").strip() == str(vpl)]
+            out["form"] = mine[-1]["form"] if mine else None
             for kind in (True, False):
                 sel = [g["bytes"] for g in mine if g["fused"] == kind]
                 out[(name, kind)] = sum(sel) / len(sel) if sel else 0.0
@@ -108,6 +111,8 @@ def main():
         o = per_step(vpl)
         nb = batches[wl]
         traffic[wl + "_per_pair"] = round((o[("FETCH_SIZE", True)] + o[("WRITE_SIZE", True)]) / nb)
+        traffic[wl + "_pairs_per_step"] = nb
+        traffic[wl + "_form"] = o["form"]
         traffic[wl + "_detail_per_pair"] = {
             "pairs_per_step_when_profiled": nb,
             "fused_fetch_bytes_corrected": round(o[("FETCH_SIZE", True)] / nb),

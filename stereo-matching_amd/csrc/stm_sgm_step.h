@@ -225,5 +225,80 @@ __device__ __forceinline__ void sgm_step_n(const Row<VPL> (&prev)[N], const Row<
   }
 }
 
+// ---------------------------------------------------------------------------------
+// One step with its front half scheduled by hand (whole lanes only; VPL = 2 or 4).
+//
+// In sgm_step every DPP instruction of the six-stage wave minimum sits behind an s_nop 1 (two
+// wait states after the VALU write of its source), and so do the two cross-lane adds: 8 of
+// the step's ~50 issue slots.  Here the slots between the minimum's stages carry the step's
+// own independent work instead -- L(d) + P1 for the lane's values, the two cross-lane adds
+// and the three-way minima that do not need the wave minimum yet -- so only the last stage
+// still waits.  Same instructions, same operands, same results; about a third fewer issue
+// slots, which is what bounds the kernels that use it.
+// ---------------------------------------------------------------------------------
+template <int VPL>
+__device__ __forceinline__ Row<VPL> sgm_step_fused(const Row<VPL> &prev, const Row<VPL> &c, float p2a,
+                                                   StepCtx &X) {
+  static_assert(VPL == 2 || VPL == 4, "hand-scheduled for two or four values per lane");
+  const float inf = __builtin_inff();
+  const float lmt = X.drop_tail ? inf : prev.v[VPL - 1];  // Q5: lane 63 leaves d = D-1 out
+  float t[VPL], m;
+  if constexpr (VPL == 4) {
+    float lm, w0, w1, w2, w3;
+    asm("v_min3_f32 %0, %15, %11, %12\n\t"
+        "v_min_f32 %0, %0, %13\n\t"
+        "v_add_f32 %1, %16, %11\n\t"
+        "v_add_f32 %2, %16, %12\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32 %3, %16, %13\n\t"
+        "v_add_f32 %4, %16, %14\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %9, %14, %17 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %10, %11, %17 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_min3_f32 %6, %12, %1, %3\n\t"
+        "v_min3_f32 %7, %13, %2, %4\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_min3_f32 %5, %11, %9, %2\n\t"
+        "v_min3_f32 %8, %14, %3, %10\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "=&v"(lm), "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3), "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]),
+          "=&v"(t[3]), "+v"(X.below), "+v"(X.above)
+        : "v"(prev.v[0]), "v"(prev.v[1]), "v"(prev.v[2]), "v"(prev.v[3]), "v"(lmt), "s"(X.p1), "v"(X.p1v));
+    m = read_lane(lm, 63);
+  } else {
+    float lm, w0, w1;
+    asm("v_min_f32 %0, %9, %7\n\t"
+        "v_add_f32 %1, %10, %7\n\t"
+        "v_add_f32 %2, %10, %8\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %5, %8, %11 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %6, %7, %11 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_min3_f32 %3, %7, %5, %2\n\t"
+        "v_min3_f32 %4, %8, %1, %6\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "=&v"(lm), "=&v"(w0), "=&v"(w1), "=&v"(t[0]), "=&v"(t[1]), "+v"(X.below), "+v"(X.above)
+        : "v"(prev.v[0]), "v"(prev.v[1]), "v"(lmt), "s"(X.p1), "v"(X.p1v));
+    m = read_lane(lm, 63);
+  }
+  const float far = m + p2a;
+  Row<VPL> cur;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const float a = c.v[j] + vmin_f32(t[j], far);
+    cur.v[j] = a - m;
+  }
+  return cur;
+}
+
 }  // namespace
 }  // namespace stm

@@ -89,52 +89,77 @@ __device__ __forceinline__ u64 *mbox_ptr(float *ws, const TiledGeom &G, int swee
                     (long long)(kMboxSlots * G.D);
 }
 
+// Two granules travel in one 16-byte write-through access where a lane holds an even number
+// of values (each 8-byte half is still written and read whole: MI355X guide, Guideline 16,
+// form R2): 8-byte stores reach the memory side as one partial write each, which the sweeps'
+// two mailboxes per strip edge and row turned into a tenth of the stage's write traffic.
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+constexpr int kAuxSc1 = 16;  // cache-policy bits of the raw buffer builtins: sc1 (write-through / L2-served)
+
 template <int VPL>
 __device__ __forceinline__ void mbox_publish(u64 *box, int D, int d0, unsigned row, const Row<VPL> &r) {
   u64 *slot = box + (size_t)(row % kMboxSlots) * D + d0;
-  const u64 tag = (u64)(row + 1) << 32;
+  const unsigned tag = row + 1;
+  if constexpr (VPL % 2 == 0) {
+    const BufRsrc rs = make_rsrc(slot - d0, (unsigned)(D * sizeof(u64)));
 #pragma unroll
-  for (int j = 0; j < VPL; ++j)
-    __hip_atomic_store(slot + j, tag | (u64)__builtin_bit_cast(unsigned, r.v[j]), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// One polling pass; true when every lane's granules carry the tag of `row`.
-template <int VPL>
-__device__ __forceinline__ bool mbox_try(const u64 *box, int D, int d0, unsigned row, Row<VPL> &r) {
-  const u64 *slot = box + (size_t)(row % kMboxSlots) * D + d0;
-  bool ok = true;
+    for (int j = 0; j < VPL; j += 2) {
+      v4u_t q;
+      q.x = __builtin_bit_cast(unsigned, r.v[j]); q.y = tag;
+      q.z = __builtin_bit_cast(unsigned, r.v[j + 1]); q.w = tag;
+      __builtin_amdgcn_raw_buffer_store_b128(q, rs, (d0 + j) * 8, 0, kAuxSc1);
+    }
+  } else {
 #pragma unroll
-  for (int j = 0; j < VPL; ++j) {
-    const u64 g = __hip_atomic_load(const_cast<u64 *>(slot) + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ok &= (unsigned)(g >> 32) == row + 1;
-    r.v[j] = __builtin_bit_cast(float, (unsigned)g);
+    for (int j = 0; j < VPL; ++j)
+      __hip_atomic_store(slot + j, ((u64)tag << 32) | (u64)__builtin_bit_cast(unsigned, r.v[j]),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  return __ballot(ok) == ~0ull;
 }
 
-// The same pass split in two, so that the loads can be issued a row's worth of work before
-// their result is needed: mbox_peek issues them, mbox_take checks and unpacks.
+// What mbox_peek brings: the raw granules of one row of a mailbox.
 template <int VPL>
 struct Granules {
-  u64 g[VPL];
+  unsigned val[VPL], tag[VPL];
 };
+// Issues the loads of one polling pass (their results may be looked at much later).
 template <int VPL>
 __device__ __forceinline__ void mbox_peek(const u64 *box, int D, int d0, unsigned row, Granules<VPL> &q) {
   const u64 *slot = box + (size_t)(row % kMboxSlots) * D + d0;
+  if constexpr (VPL % 2 == 0) {
+    const BufRsrc rs = make_rsrc(slot - d0, (unsigned)(D * sizeof(u64)));
 #pragma unroll
-  for (int j = 0; j < VPL; ++j)
-    q.g[j] = __hip_atomic_load(const_cast<u64 *>(slot) + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int j = 0; j < VPL; j += 2) {
+      const v4u_t g = __builtin_amdgcn_raw_buffer_load_b128(rs, (d0 + j) * 8, 0, kAuxSc1);
+      q.val[j] = g.x; q.tag[j] = g.y;
+      q.val[j + 1] = g.z; q.tag[j + 1] = g.w;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+      const u64 g = __hip_atomic_load(const_cast<u64 *>(slot) + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      q.val[j] = (unsigned)g;
+      q.tag[j] = (unsigned)(g >> 32);
+    }
+  }
 }
+// True when every lane's granules carry the tag of `row`; r then holds the values.
 template <int VPL>
 __device__ __forceinline__ bool mbox_take(const Granules<VPL> &q, unsigned row, Row<VPL> &r) {
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < VPL; ++j) {
-    ok &= (unsigned)(q.g[j] >> 32) == row + 1;
-    r.v[j] = __builtin_bit_cast(float, (unsigned)q.g[j]);
+    ok &= q.tag[j] == row + 1;
+    r.v[j] = __builtin_bit_cast(float, q.val[j]);
   }
   return __ballot(ok) == ~0ull;
+}
+// One polling pass.
+template <int VPL>
+__device__ __forceinline__ bool mbox_try(const u64 *box, int D, int d0, unsigned row, Row<VPL> &r) {
+  Granules<VPL> q;
+  mbox_peek<VPL>(box, D, d0, row, q);
+  return mbox_take<VPL>(q, row, r);
 }
 
 // Waits for the neighbour's row `row`.  Bounded: after ~2 s (s_memrealtime runs at 100 MHz)
@@ -805,13 +830,23 @@ __device__ __forceinline__ void tile_chains_fast(const Slots<PHASE> &sl, const E
     const int qx = px + (inv ? dx : -dx), qy = py + (inv ? dy : -dy);
     pen = sgm_penalty(Ip[(py + 1) * (kT + 2) + px + 1], Ip[(qy + 1) * (kT + 2) + qx + 1], p1, p2);
   }
+  // The cost row of the next slot is requested before the current step runs: with sixteen
+  // waves on the LDS a read takes a few hundred cycles, which a step issued behind it would
+  // wait out once per slot.
+  auto step = [&](const Row<VPL> &prev, const Row<VPL> &c, float p2a) {
+    if constexpr (VPL >= 2) return sgm_step_fused<VPL>(prev, c, p2a, X);
+    else return sgm_step<VPL, true>(prev, c, p2a, X);
+  };
   Row<VPL> pf = E.e[0];
+  Row<VPL> cn = lds_row<VPL>(Ct, sl.pix[0], d0);
 #pragma unroll
   for (int s = 0; s < kT; ++s) {
     if constexpr (PHASE >= 2) {
       if (s > 0 && s == nA) pf = E.e[2];
     }
-    pf = sgm_step<VPL, true>(pf, lds_row<VPL>(Ct, sl.pix[s], d0), read_lane(pen, s), X);
+    const Row<VPL> c = cn;
+    cn = lds_row<VPL>(Ct, sl.pix[s < kT - 1 ? s + 1 : kT - 1], d0);  // after slot 7: slot 7 again, for I
+    pf = step(pf, c, read_lane(pen, s));
     LF[s] = pf;
   }
   Row<VPL> pi;
@@ -822,7 +857,9 @@ __device__ __forceinline__ void tile_chains_fast(const Slots<PHASE> &sl, const E
     if constexpr (PHASE >= 2) {
       if (s < kT - 1 && s == nA - 1) pi = E.e[1];
     }
-    pi = sgm_step<VPL, true>(pi, lds_row<VPL>(Ct, sl.pix[s], d0), read_lane(pen, 8 + s), X);
+    const Row<VPL> c = cn;
+    if (s > 0) cn = lds_row<VPL>(Ct, sl.pix[s - 1], d0);
+    pi = step(pi, c, read_lane(pen, 8 + s));
     LI[s] = pi;
   }
 }
@@ -834,6 +871,8 @@ __device__ __forceinline__ void tile_add_fast(const Slots<PHASE> &sl, const Row<
                                               float *__restrict__ out, int32_t *__restrict__ disp, int lane) {
   constexpr int D = 64 * VPL;
   const int d0 = lane * VPL;
+  Row<VPL> sn;
+  if (PHASE != 0) sn = lds_row<VPL>(St, sl.pix[0], d0);
 #pragma unroll
   for (int s = 0; s < kT; ++s) {
     const int pix = sl.pix[s];
@@ -842,7 +881,8 @@ __device__ __forceinline__ void tile_add_fast(const Slots<PHASE> &sl, const Row<
 #pragma unroll
       for (int j = 0; j < VPL; ++j) acc.v[j] = 0.0f;
     } else {
-      acc = lds_row<VPL>(St, pix, d0);
+      acc = sn;
+      if (s < kT - 1) sn = lds_row<VPL>(St, sl.pix[s + 1], d0);  // the next slot's sum, early
     }
 #pragma unroll
     for (int j = 0; j < VPL; ++j) acc.v[j] = (acc.v[j] + LF[s].v[j]) + LI[s].v[j];
