@@ -207,10 +207,10 @@ struct SweepArgs {
 #ifdef STM_TILE_STAMPS
 #define STM_SWEEP_STAMP(k)                                                                   \
   do {                                                                                       \
-    if (P.stamps && !UP && blockIdx.y == 0 && s < 8 && t >= 500 && t < 516 && lane == 0) {   \
+    if (P.stamps && !UP && blockIdx.y == 0 && s < 8 && t >= 100 && t < 116 && lane == 0) {   \
       unsigned long long t_;                                                                 \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");           \
-      P.stamps[(((size_t)s * NW + wv) * 16 + (t - 500)) * 8 + (k)] = t_;                     \
+      P.stamps[(((size_t)s * NW + wv) * 16 + (t - 100)) * 8 + (k)] = t_;                     \
     }                                                                                        \
   } while (0)
 #else
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float
   auto fetch = [&](int t, Row<VPL> (&dst)[CW]) {
     const int base = wave_uniform(row_of(imin(t, H - 1)) * row_elems);
 #pragma unroll
-    for (int j = 0; j < CW; ++j) dst[j] = load_row_at<VPL, true>(cost, (long)(unsigned)(base + xoff[j]), D, d0);
+    for (int j = 0; j < CW; ++j) dst[j] = load_row_at<VPL, true, true>(cost, (long)(unsigned)(base + xoff[j]), D, d0);
   };
   // Intensities for the 3*CW penalties of a row: lane l serves column l/3, direction l%3
   // (0 V, 1 A, 2 B) and reads its pixel and that pixel's predecessor on the path.
@@ -286,6 +286,131 @@ __global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float
   Row<VPL> cb[PF + 1][CW];
   float ic[PF + 1], ip[PF + 1];
   Granules<VPL> qa, qb;
+
+  // The common case gets a loop of its own: every column of the wave inside the image and none
+  // of them in image column 0 or W-1, so no path starts here and nothing is clipped.  At
+  // D <= 128 the sweep is bound by instruction issue (16 waves x ~800 instructions per row of the
+  // generic loop below), and what that loop spends on start / validity selects and on
+  // recomputing 64-bit addresses every row is row time; at D = 256 the sweep is HBM-bound and
+  // the two loops take the same time.
+  if (VPL <= 2 && xa >= 1 && xa + CW <= W - 1) {
+    const long row_step = (long)(UP ? -1 : 1) * W * D;  // elements from one row to the next
+    const float *cnext = cost + (size_t)(UP ? H - 1 : 0) * W * D + (size_t)xa * D + d0;  // this lane's part of the next row to fetch
+    int t_next = 0;
+    // Intensity samples of this lane's penalty (cur: pixel xa + pj of the row, prv: its
+    // predecessor on the path, one row back).
+    const float *inext = image + (size_t)(UP ? H - 1 : 0) * W;
+    const int istep = UP ? -W : W;
+    auto refill = [&](Row<VPL> (&dst)[CW], float &icur, float &iprev) {
+      icur = inext[px];
+      iprev = (t_next > 0 ? inext - istep : inext)[pxs];
+#pragma unroll
+      for (int j = 0; j < CW; ++j) dst[j] = load_row<VPL, true, true>(cnext + j * D, 0, D, 0);
+      if (t_next < H - 1) { cnext += row_step; inext += istep; }  // past the end: the last row again (unused)
+      ++t_next;
+    };
+    // Border-state destinations.  Column lines: A where x % 8 == 7, B where x % 8 == 0 (at most
+    // one of each among CW <= 8 columns), advancing by one line row per image row.
+    int ja_col = -1, jb_col = -1;
+#pragma unroll
+    for (int j = 0; j < CW; ++j) {
+      if (((xa + j) & (kT - 1)) == kT - 1) ja_col = j;
+      if (((xa + j) & (kT - 1)) == 0) jb_col = j;
+    }
+    const int y_first = UP ? H - 1 : 0;
+    float *colA = ja_col >= 0 ? colb_ptr(ws, G, b, UP ? 2 : 1, (xa + ja_col) >> 3, y_first) + d0 : nullptr;
+    float *colB = jb_col >= 0 ? colb_ptr(ws, G, b, UP ? 5 : 4, (xa + jb_col) >> 3, y_first) + d0 : nullptr;
+    const int col_step = UP ? -D : D;
+    float *rowV = rowb_ptr(ws, G, b, UP ? 3 : 0, 0, xa) + d0;  // line 0; line t is t * W * D further
+    const long long kstride = (long long)G.nTR * W * D;
+
+#pragma unroll
+    for (int u = 0; u <= PF; ++u) refill(cb[u], ic[u], ip[u]);
+    int y = y_first;
+    for (int t0 = 0; t0 < H; t0 += PF + 1) {
+#pragma unroll
+      for (int u = 0; u <= PF; ++u) {
+        const int t = t0 + u;
+        if (t < H) {
+          const int par = t & 1;
+          STM_SWEEP_STAMP(0);
+          const float pen = sgm_penalty(ic[u], ip[u], P.p1, P.p2);
+          if (t == 0) {
+#pragma unroll
+            for (int j = 0; j < CW; ++j) { V[j] = cb[u][j]; A[j] = cb[u][j]; B[j] = cb[u][j]; }
+            if (pubA) mbox_publish<VPL>(pubA, D, d0, 0u, A[CW - 1]);
+            if (pubB) mbox_publish<VPL>(pubB, D, d0, 0u, B[0]);
+            store_row<VPL, true>(&xch[par][0][wv][0], 0, D, d0, A[CW - 1]);
+            store_row<VPL, true>(&xch[par][1][wv][0], 0, D, d0, B[0]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < CW; ++i) {
+              const int ja = CW - 1 - i, jb = i;
+              Row<VPL> prev[3], cc[3], cur[3];
+              prev[0] = V[i];
+              cc[0] = cb[u][i];
+              cc[1] = cb[u][ja];
+              cc[2] = cb[u][jb];
+              if (i < CW - 1) {
+                prev[1] = A[ja - 1];
+                prev[2] = B[jb + 1];
+              } else {
+                STM_SWEEP_STAMP(2);
+                if (left_lds) prev[1] = load_row<VPL, true>(&xch[par ^ 1][0][wv - 1][0], 0, D, d0);
+                else if (dead || !mbox_take<VPL>(qa, (unsigned)(t - 1), prev[1]))
+                  mbox_wait<VPL>(subA, D, d0, (unsigned)(t - 1), prev[1], dead, status);
+                if (right_lds) prev[2] = load_row<VPL, true>(&xch[par ^ 1][1][wv + 1][0], 0, D, d0);
+                else if (dead || !mbox_take<VPL>(qb, (unsigned)(t - 1), prev[2]))
+                  mbox_wait<VPL>(subB, D, d0, (unsigned)(t - 1), prev[2], dead, status);
+                STM_SWEEP_STAMP(3);
+              }
+              const float p2a[3] = {read_lane(pen, 3 * i), read_lane(pen, 3 * ja + 1),
+                                    read_lane(pen, 3 * jb + 2)};
+              sgm_step_n<VPL, 3>(prev, cc, p2a, X, cur);
+              V[i] = cur[0];
+              A[ja] = cur[1];
+              B[jb] = cur[2];
+              if (i == 0) {
+                if (pubA) mbox_publish<VPL>(pubA, D, d0, (unsigned)t, A[CW - 1]);
+                if (pubB) mbox_publish<VPL>(pubB, D, d0, (unsigned)t, B[0]);
+                store_row<VPL, true>(&xch[par][0][wv][0], 0, D, d0, A[CW - 1]);
+                store_row<VPL, true>(&xch[par][1][wv][0], 0, D, d0, B[0]);
+                STM_SWEEP_STAMP(1);
+              }
+            }
+          }
+          STM_SWEEP_STAMP(4);
+          if (!dead && t + 1 < H) {
+            if (subA) mbox_peek<VPL>(subA, D, d0, (unsigned)t, qa);
+            if (subB) mbox_peek<VPL>(subB, D, d0, (unsigned)t, qb);
+          }
+          if ((y & (kT - 1)) == (UP ? 0 : kT - 1)) {
+            float *r0 = rowV + (long long)(y >> 3) * W * D;
+#pragma unroll
+            for (int j = 0; j < CW; ++j) {
+              store_row<VPL, true, true>(r0 + j * D, 0, D, 0, V[j]);
+              store_row<VPL, true, true>(r0 + kstride + j * D, 0, D, 0, A[j]);
+              store_row<VPL, true, true>(r0 + 2 * kstride + j * D, 0, D, 0, B[j]);
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < CW; ++j) {
+            if (j == ja_col) store_row<VPL, true, true>(colA, 0, D, 0, A[j]);
+            if (j == jb_col) store_row<VPL, true, true>(colB, 0, D, 0, B[j]);
+          }
+          if (colA) colA += col_step;
+          if (colB) colB += col_step;
+          y += UP ? -1 : 1;
+          // This row's cost registers are free now: fetch row t + PF + 1 into them.
+          refill(cb[u], ic[u], ip[u]);
+          STM_SWEEP_STAMP(5);
+          lds_barrier();
+          STM_SWEEP_STAMP(6);
+        }
+      }
+    }
+    return;
+  }
 
   if (active) {
 #pragma unroll
@@ -384,9 +509,9 @@ __global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float
               if (xa + j < W) {
                 float *r0 = rowb_ptr(ws, G, b, UP ? 3 : 0, y >> 3, xa + j);
                 const long long kstride = (long long)G.nTR * G.W * D;
-                store_row<VPL, true>(r0, 0, D, d0, V[j]);
-                store_row<VPL, true>(r0 + kstride, 0, D, d0, A[j]);
-                store_row<VPL, true>(r0 + 2 * kstride, 0, D, d0, B[j]);
+                store_row<VPL, true, true>(r0, 0, D, d0, V[j]);
+                store_row<VPL, true, true>(r0 + kstride, 0, D, d0, A[j]);
+                store_row<VPL, true, true>(r0 + 2 * kstride, 0, D, d0, B[j]);
               }
             }
           }
@@ -394,9 +519,9 @@ __global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float
           for (int j = 0; j < CW; ++j) {
             const int x = xa + j;
             if (x < W && (x & (kT - 1)) == kT - 1)
-              store_row<VPL, true>(colb_ptr(ws, G, b, UP ? 2 : 1, x >> 3, y), 0, D, d0, A[j]);
+              store_row<VPL, true, true>(colb_ptr(ws, G, b, UP ? 2 : 1, x >> 3, y), 0, D, d0, A[j]);
             if (x < W && (x & (kT - 1)) == 0)
-              store_row<VPL, true>(colb_ptr(ws, G, b, UP ? 5 : 4, x >> 3, y), 0, D, d0, B[j]);
+              store_row<VPL, true, true>(colb_ptr(ws, G, b, UP ? 5 : 4, x >> 3, y), 0, D, d0, B[j]);
           }
         }
         // One barrier per row: xch[par] written in this row is read in the next one, and
@@ -423,7 +548,11 @@ template <int VPL>
 __global__ __launch_bounds__(256) void sgm_hwalk_kernel(const float *__restrict__ cost_all,
                                                         const float *__restrict__ image_all,
                                                         float *__restrict__ ws, const HwalkArgs P) {
+#ifdef STM_HWALK_RECOMPUTE_PROBE
+  constexpr int PF = 16;  // = the register ring of window columns (14 used)
+#else
   constexpr int PF = 8;
+#endif
   constexpr int D = 64 * VPL;
   const TiledGeom &G = P.G;
   const int lane = threadIdx.x & 63;
@@ -454,6 +583,15 @@ __global__ __launch_bounds__(256) void sgm_hwalk_kernel(const float *__restrict_
 #pragma unroll
   for (int u = 0; u < PF; ++u) cbuf[u] = load_row<VPL, true>(cost, (size_t)col_of(imin(u, last)), D, d0);
   Row<VPL> prev = cbuf[0];
+#ifdef STM_HWALK_RECOMPUTE_PROBE
+  __shared__ float probe_lds_all[4][14 * (D + 64) + 64];
+  float *probe_lds = probe_lds_all[threadIdx.x >> 6];
+  for (int e = lane; e < 14 * (D + 64) + 64; e += 64) probe_lds[e] = (float)((e * 7 + y) & 255);
+  float probe_left = (float)((lane * 13 + y) & 255);
+  Row<VPL> probe_acc = cbuf[0], probe_ring[PF];
+#pragma unroll
+  for (int u = 0; u < PF; ++u) probe_ring[u] = cbuf[u];
+#endif
   const int keep = left ? 0 : kT - 1;
   const int k = left ? 3 : 0;
   for (int base = 0; base < W; base += PF) {
@@ -465,11 +603,44 @@ __global__ __launch_bounds__(256) void sgm_hwalk_kernel(const float *__restrict_
     for (int u = 0; u < PF; ++u) {
       const int i = base + u;
       if (i < W) {
+#ifdef STM_HWALK_RECOMPUTE_PROBE
+        // Timing probe (tools/build_probe.sh recompute; never in the product): what the walk
+        // would cost if it rebuilt the SSD cost of its pixel instead of loading it.  The
+        // arithmetic of the integer-exact sliding form along a row: one new window column per
+        // step = 14 rows x (left sample by v_readlane, right samples of the lane's
+        // disparities by one 16-byte LDS read, subtract, multiply, add), plus the leaving
+        // column from a 16-deep register ring.  The staged data is synthetic (no image rows
+        // are loaded or staged, which a real kernel would have to do on top), so the result is
+        // meaningless and only the kernel's time is looked at: a lower bound.
+        Row<VPL> c;
+        {
+          Row<VPL> col;
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) col.v[j] = 0.0f;
+#pragma unroll
+          for (int kr = 0; kr < 14; ++kr) {
+            const float lv = read_lane(probe_left, (kr + u) & 63);
+            const Row<VPL> rv = load_row<VPL, true>(probe_lds + kr * (D + 64) + 4 * ((i + kr) & 15), 0, D, d0);
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+              const float t = lv - rv.v[j];
+              col.v[j] = col.v[j] + t * t;
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < VPL; ++j) {
+            probe_acc.v[j] = (probe_acc.v[j] + col.v[j]) - probe_ring[u].v[j];
+            probe_ring[u].v[j] = col.v[j];
+            c.v[j] = probe_acc.v[j];
+          }
+        }
+#else
         const Row<VPL> c = cbuf[u];
-        cbuf[u] = load_row<VPL, true>(cost, (size_t)col_of(imin(i + PF, last)), D, d0);
+        cbuf[u] = load_row<VPL, true, true>(cost, (size_t)col_of(imin(i + PF, last)), D, d0);
+#endif
         if (i > 0) prev = sgm_step<VPL, true>(prev, c, read_lane(pen, i & (kWave - 1)), X);
         const int x = col_of(i);
-        if ((x & (kT - 1)) == keep) store_row<VPL, true>(colb_ptr(ws, G, b, k, x >> 3, y), 0, D, d0, prev);
+        if ((x & (kT - 1)) == keep) store_row<VPL, true, true>(colb_ptr(ws, G, b, k, x >> 3, y), 0, D, d0, prev);
       }
     }
   }
@@ -814,7 +985,7 @@ __device__ __forceinline__ void tile_add(const PhaseGeom &g, const Slots<PHASE> 
 // diagonal pairs the second segment begins at slot nA (nA = 8: there is none).
 template <int VPL, int PHASE>
 __device__ __forceinline__ void tile_chains_fast(const Slots<PHASE> &sl, const Entries<VPL, PHASE> &E,
-                                                 const float *Ct, const float *Ip, float p1, float p2,
+                                                 bool inv_a, bool inv_b, const float *Ct, const float *Ip, float p1, float p2,
                                                  StepCtx &X, int lane, Row<VPL> (&LF)[kT], Row<VPL> (&LI)[kT]) {
   constexpr int dx = PhaseDir<PHASE>::dx, dy = PhaseDir<PHASE>::dy;
   const int d0 = lane * VPL;
@@ -859,15 +1030,18 @@ __device__ __forceinline__ void tile_chains_fast(const Slots<PHASE> &sl, const E
     }
     const Row<VPL> c = cn;
     if (s > 0) cn = lds_row<VPL>(Ct, sl.pix[s - 1], d0);
-    pi = step(pi, c, read_lane(pen, 8 + s));
-    LI[s] = pi;
+    // A segment whose inverse pass the reference never runs (inv_a / inv_b false) is skipped.
+    if (PHASE < 2 || (s < nA ? inv_a : inv_b)) {
+      pi = step(pi, c, read_lane(pen, 8 + s));
+      LI[s] = pi;
+    }
   }
 }
 
 // ... and the sum update when every direction counts once: S = (S + F) + I.
 template <int VPL, int PHASE, int FINAL>
 __device__ __forceinline__ void tile_add_fast(const Slots<PHASE> &sl, const Row<VPL> (&LF)[kT],
-                                              const Row<VPL> (&LI)[kT], float *St, int W, int x0, int y0,
+                                              const Row<VPL> (&LI)[kT], bool inv_a, bool inv_b, float *St, int W, int x0, int y0,
                                               float *__restrict__ out, int32_t *__restrict__ disp, int lane) {
   constexpr int D = 64 * VPL;
   const int d0 = lane * VPL;
@@ -885,7 +1059,11 @@ __device__ __forceinline__ void tile_add_fast(const Slots<PHASE> &sl, const Row<
       if (s < kT - 1) sn = lds_row<VPL>(St, sl.pix[s + 1], d0);  // the next slot's sum, early
     }
 #pragma unroll
-    for (int j = 0; j < VPL; ++j) acc.v[j] = (acc.v[j] + LF[s].v[j]) + LI[s].v[j];
+    for (int j = 0; j < VPL; ++j) acc.v[j] = acc.v[j] + LF[s].v[j];
+    if (PHASE < 2 || (s < sl.nA ? inv_a : inv_b)) {
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) acc.v[j] = acc.v[j] + LI[s].v[j];
+    }
     if (PHASE < 3) {
       store_row<VPL, true>(St + (size_t)pix * D, 0, D, d0, acc);
     } else {
@@ -918,16 +1096,23 @@ __device__ __forceinline__ void tile_pair(const PhaseGeom &g, const Entries<VPL,
   Row<VPL> LF[kT], LI[kT];
   Slots<PHASE> sl;
   sl.init(g);
+  // Fast forms: full tile, no path begins in it, every inverse pass counts once or not at all
+  // (the reference skips the inverse diagonals of 17-44 % of a wide image's pixels, Q6: those
+  // segments' I chains are not even computed); what is left for the generic forms are the
+  // tiles on the image border and on the re-walked corner diagonals.
   bool fast = full && E.start == 0;
+  bool inv_a = true, inv_b = true;
   if (PHASE >= 2 && fast) {
     const Counts ca = seg_counts<PHASE>(g.a, x0, y0, P.G, P.true_paths);
     const Counts cb = seg_counts<PHASE>(g.b, x0, y0, P.G, P.true_paths);
-    fast = ca.inv == 1 && ca.pre == 0 && cb.inv == 1 && cb.pre == 0;
+    fast = ca.inv <= 1 && ca.pre == 0 && cb.inv <= 1 && cb.pre == 0;
+    inv_a = ca.inv != 0;
+    inv_b = cb.inv != 0;
   }
   if (fast) {
-    tile_chains_fast<VPL, PHASE>(sl, E, Ct, Ip, P.p1, P.p2, X, lane, LF, LI);
+    tile_chains_fast<VPL, PHASE>(sl, E, inv_a, inv_b, Ct, Ip, P.p1, P.p2, X, lane, LF, LI);
     between();
-    tile_add_fast<VPL, PHASE, FINAL>(sl, LF, LI, St, P.G.W, x0, y0, out, disp, lane);
+    tile_add_fast<VPL, PHASE, FINAL>(sl, LF, LI, inv_a, inv_b, St, P.G.W, x0, y0, out, disp, lane);
   } else {
     tile_chains<VPL, PHASE>(sl, E, Ct, Ip, P.p1, P.p2, X, lane, LF, LI);
     between();
@@ -973,7 +1158,9 @@ struct TileWalk {
 };
 
 template <int VPL, int FINAL>
-__global__ __launch_bounds__(2 * kT * 64) void sgm_tile_kernel(const float *__restrict__ cost_all,
+// (the second launch bound asks for two resident workgroups per CU where the LDS allows
+// them, D <= 128: 8 waves per SIMD, i.e. at most 64 VGPRs)
+__global__ __launch_bounds__(2 * kT * 64, VPL >= 4 ? 4 : 8) void sgm_tile_kernel(const float *__restrict__ cost_all,
                                                                const float *__restrict__ image_all,
                                                                float *__restrict__ out_all,
                                                                int32_t *__restrict__ disp_all,
@@ -1234,13 +1421,14 @@ bool sgm_tiled_selected(int H, int W, int D, int batch, int flags) {
   if (!make_plan(H, W, D, batch, plan)) return false;
   if (flags & STM_SGM_TILED) return true;
   // Measured on MI355X (tools/sgm_forms.py): the tiled form wins where the volume traffic it
-  // saves outweighs its fixed costs per image row and per tile -- D = 256 with enough columns
-  // in the batch to keep the row sweeps' column strips on most CUs (1080p: from 3 pairs; 4.3
-  // against 5.8 ms per pair at 8-16 pairs, 8.0 against 6.0 ms for a single pair).  At D = 128 the
-  // two forms are level and at D = 64 the paired form is faster, so they stay with it.
+  // saves outweighs its fixed costs per image row and per tile, i.e. for wide disparity ranges
+  // with enough columns in the batch to keep the row sweeps' column strips on most CUs:
+  // D = 256: from 3 pairs at 1080p (4.0 against 5.8 ms per pair at 8-16 pairs; 8.0 against 6.0 ms
+  // for a single pair); D = 128: 7-9 % ahead on large batches (Teddy x 256: 51.7 against 55.6 ms);
+  // D = 64: the paired form is 1.4x faster and keeps the job.
   const int cus = device_cus();
   const int strip_cols = kSweepWaves * sweep_cw(D / 64);
-  return D == 256 && (long long)batch * W * 2 >= (long long)cus * strip_cols && H >= 64;
+  return D >= 128 && (long long)batch * W * 2 >= (long long)cus * strip_cols && H >= 64;
 }
 
 size_t sgm_tiled_workspace_bytes(int H, int W, int D, int batch, int flags) {

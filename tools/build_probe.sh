@@ -8,6 +8,11 @@ mkdir -p $ROOT/tools/_probe /tmp/isa
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -I$ROOT/include -I$C"
 /opt/rocm/bin/hipcc $FL -DSTM_TILE_STAMPS -c $C/stm_sgm_tiled.hip -o /tmp/isa/tiled_stamps.o 2>&1 | grep -E "error|warning:" || true
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/tools/_probe/libstm_stamps.so $C/stm_api.o $C/stm_wta.o $C/stm_ssd.o $C/stm_birchfield.o $C/stm_sgm.o /tmp/isa/tiled_stamps.o $C/stm_dp.o $C/stm_sgm_exact.o
+if [ "$1" = "recompute" ]; then
+  # the horizontal walk with the arithmetic of an in-walk SSD recomputation (timing probe)
+  /opt/rocm/bin/hipcc $FL -DSTM_HWALK_RECOMPUTE_PROBE -c $C/stm_sgm_tiled.hip -o /tmp/isa/tiled_recompute.o 2>&1 | grep -E "error|warning:" || true
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/tools/_probe/libstm_recompute.so $C/stm_api.o $C/stm_wta.o $C/stm_ssd.o $C/stm_birchfield.o $C/stm_sgm.o /tmp/isa/tiled_recompute.o $C/stm_dp.o $C/stm_sgm_exact.o
+fi
 if [ "$1" = "usage" ]; then
   /opt/rocm/bin/hipcc $FL --cuda-device-only -S $C/stm_sgm_tiled.hip -o /tmp/isa/tiled.s -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "Function Name|VGPRs:|Spill|Scratch" | sed 's/.*remark: *//; s/ \[-Rpass.*//' | paste - - - - - | sed 's/_ZN3stm12_GLOBAL__N_1//; s/EvPKfS3.*E\t/\t/' | grep -E "ILi[24]E"
 fi
