@@ -143,7 +143,7 @@ int stm_birchfield_ex_f32(const float *left, const float *right, float *cost,
  * per path; any shape) and the tiled form (row sweeps + 8x8-pixel tiles: the cost volume is
  * read five times, the sum never travels: 32-36 instead of 56-60 bytes per element; covers
  * D = 64, 128 or 256 without ACCUMULATE / SINGLE_PASSES / EXACT_NONFINITE, chosen by default
- * for D = 256 with enough columns in the batch to fill the chip).  Same results bit for bit.
+ * for D >= 128 with enough columns in the batch to fill the chip).  Same results bit for bit.
  *   STM_SGM_PAIRED  never use the tiled form.
  *   STM_SGM_TILED   use the tiled form whenever it covers the call, whatever the batch size.
  * Both flags must be passed identically to stm_sgm_workspace_bytes().
@@ -154,7 +154,11 @@ int stm_birchfield_ex_f32(const float *left, const float *right, float *cost,
  * wait that expires sets bit 0 (the results of that call are then invalid).  It can only
  * happen when the launch's workgroups cannot all be resident (e.g. the device is shared with
  * another long-running kernel).  The entry points never synchronise, so the word is for the
- * caller to inspect after its next synchronisation (stm_sgm_status). */
+ * caller to inspect after its next synchronisation (stm_sgm_status).
+ * Run at most ONE tiled aggregation at a time per device: two of them in flight together (two
+ * streams, or two processes on one GPU) can each hold a part of the CUs and wait for the
+ * other's until both time out.  Calls on one stream, other kernels beside it, and the paired
+ * form are unaffected. */
 #define STM_SGM_PAIRED 64
 #define STM_SGM_TILED 128
 size_t stm_sgm_workspace_bytes(int H, int W, int D, int batch, int flags);
