@@ -45,7 +45,9 @@ def test_fuzz_all_ops(device, oracle, H, W, D):
         assert_same_bits(got.cpu().numpy(), want_C, "ssd k=%d %s %s" % (k, kind, mode))
     bt = stereomatch.cost.Birchfield(D)(Lg, Rg)
     assert_same_bits(bt.cpu().numpy(), oracle.birchfield(L, R, D), "birchfield")
-    vol = _random_volume(rng, H, W, D, ["float", "ties", "inf", "last"][int(rng.integers(0, 4))])
+    vol_kind = ["float", "ties", "inf", "last"][int(rng.integers(0, 4))]
+    vol = _random_volume(rng, H, W, D, vol_kind)
+    vol_raw = vol.copy()  # with its all-+inf pixels: for the exact non-finite variant below
     # Like every volume the cost ops produce, d = 0 is finite at every pixel.  A pixel whose
     # costs are all +inf makes the reference's recurrence emit inf - inf: NaN and -inf then
     # spread along every path through it, and which of them lands where depends on how
@@ -61,6 +63,15 @@ def test_fuzz_all_ops(device, oracle, H, W, D):
         S = stereomatch.aggregation.Semiglobal(p1, p2, single_passes=single, paths=paths,
                                                full_min=full_min)(vg, ig)
         assert_same_bits(S.cpu().numpy(), want_S, "sgm single=%s %s full_min=%s" % (single, paths, full_min))
+    if vol_kind == "inf":
+        # STM_SGM_EXACT_NONFINITE on the UNPATCHED volume (30 % +inf entries, an all-+inf pixel):
+        # NaN, -inf and +inf land where the reference puts them, in both forms of the kernels.
+        raw_g = _gpu(vol_raw, device)
+        want_raw = oracle.sgm(vol_raw, image, p1, p2, full_min=full_min, true_paths=(paths == "hirschmuller"))
+        for single in (False, True):
+            S = stereomatch.aggregation.Semiglobal(p1, p2, single_passes=single, paths=paths,
+                                                   full_min=full_min, exact_nonfinite=True)(raw_g, ig)
+            assert_same_bits(S.cpu().numpy(), want_raw, "sgm exact non-finite single=%s" % single)
     # The reducers run on a NaN-free volume: NaN handling differs by design in SGM/DP.
     red = np.where(np.isnan(want_S), np.float32(np.inf), want_S).astype(np.float32)
     rg = _gpu(red, device)
