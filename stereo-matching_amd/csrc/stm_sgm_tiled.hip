@@ -1109,6 +1109,22 @@ __device__ __forceinline__ void tile_pair(const PhaseGeom &g, const Entries<VPL,
     inv_a = ca.inv != 0;
     inv_b = cb.inv != 0;
   }
+#ifdef STM_TILE_ABLATE
+  // Timing ablations (tools/build_probe.sh ablate; results are wrong, only times are read):
+  // 1 = no sum updates, 2 = no chains, 4 = no final output / winner-takes-all.
+  if (fast) {
+    if (!(STM_TILE_ABLATE & 2)) tile_chains_fast<VPL, PHASE>(sl, E, inv_a, inv_b, Ct, Ip, P.p1, P.p2, X, lane, LF, LI);
+    else {
+#pragma unroll
+      for (int q = 0; q < kT; ++q) { LF[q] = E.e[0]; LI[q] = E.e[1]; }
+    }
+    between();
+    if (!(STM_TILE_ABLATE & 1) && !((STM_TILE_ABLATE & 4) && PHASE == 3))
+      tile_add_fast<VPL, PHASE, FINAL>(sl, LF, LI, inv_a, inv_b, St, P.G.W, x0, y0, out, disp, lane);
+    else if (lane == 0 && LF[0].v[0] + LI[7].v[0] == 12345.678f) St[0] = 1.0f;  // keeps the chains alive
+    return;
+  }
+#endif
   if (fast) {
     tile_chains_fast<VPL, PHASE>(sl, E, inv_a, inv_b, Ct, Ip, P.p1, P.p2, X, lane, LF, LI);
     between();

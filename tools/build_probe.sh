@@ -1,5 +1,6 @@
 #!/bin/bash
-# Builds the product library and the diagnostic (stamped) variant tools/_probe/libstm_stamps.so.
+# Builds the product library and the diagnostic (stamped) variant tools/_probe/libstm_stamps.so;
+# options: usage (register / scratch use), recompute, ablate (timing probes, see below).
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 C=$ROOT/stereo-matching_amd/csrc
@@ -12,6 +13,14 @@ if [ "$1" = "recompute" ]; then
   # the horizontal walk with the arithmetic of an in-walk SSD recomputation (timing probe)
   /opt/rocm/bin/hipcc $FL -DSTM_HWALK_RECOMPUTE_PROBE -c $C/stm_sgm_tiled.hip -o /tmp/isa/tiled_recompute.o 2>&1 | grep -E "error|warning:" || true
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/tools/_probe/libstm_recompute.so $C/stm_api.o $C/stm_wta.o $C/stm_ssd.o $C/stm_birchfield.o $C/stm_sgm.o /tmp/isa/tiled_recompute.o $C/stm_dp.o $C/stm_sgm_exact.o
+fi
+if [ "$1" = "ablate" ]; then
+  # the tile kernel without its sum updates (1), its chains (2), both (3), its final output and
+  # winner-takes-all (4): timing ablations, results are wrong (tools/time_libs.sh "ablate1 ...")
+  for A in 1 2 3 4; do
+    /opt/rocm/bin/hipcc $FL -DSTM_TILE_ABLATE=$A -c $C/stm_sgm_tiled.hip -o /tmp/isa/tiled_ablate$A.o 2>&1 | grep -E "error|warning:" || true
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/tools/_probe/libstm_ablate$A.so $C/stm_api.o $C/stm_wta.o $C/stm_ssd.o $C/stm_birchfield.o $C/stm_sgm.o /tmp/isa/tiled_ablate$A.o $C/stm_dp.o $C/stm_sgm_exact.o
+  done
 fi
 if [ "$1" = "usage" ]; then
   /opt/rocm/bin/hipcc $FL --cuda-device-only -S $C/stm_sgm_tiled.hip -o /tmp/isa/tiled.s -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "Function Name|VGPRs:|Spill|Scratch" | sed 's/.*remark: *//; s/ \[-Rpass.*//' | paste - - - - - | sed 's/_ZN3stm12_GLOBAL__N_1//; s/EvPKfS3.*E\t/\t/' | grep -E "ILi[24]E"
