@@ -103,6 +103,7 @@ class Job:
         self.stage = None
         self.pending = None
         self.n_elems = H * W * D
+        self.D = D
 
     def step(self, events=None, world=1, gather=None):
         ev = events
@@ -181,7 +182,8 @@ def roofline(job, sgm_ms, traffic_and_note=(None, None)):
     algorithmic = 8.0 * job.n_elems * job.batch  # read cost once + write sum once
     achieved = algorithmic / (sgm_ms * 1e-3) / 1e9
     tiled = bool(getattr(job.sgm, "_last_tiled", False))
-    kernels = ("tiled form: sgm_hwalk_kernel + sgm_sweep_kernel (down, up) + sgm_tile_kernel" if tiled
+    tile = "sgm_tile_h2_kernel" if getattr(job, "D", 0) == 128 else "sgm_tile_kernel"
+    kernels = ("tiled form: sgm_hwalk_kernel + sgm_sweep_kernel (down, up) + " + tile if tiled
                else "paired form: sgm_ckpt_kernel + 4 x sgm_pair_kernel")
     return {"bound": "hbm", "traffic_note": note,
             "kernel": "semiglobal aggregation with fused WTA (stm_sgm_wta_f32), " + kernels,

@@ -78,7 +78,8 @@ def main():
     # HBM bytes per aggregation call: dispatches in order; a call begins with sgm_hwalk_kernel
     # (tiled form: + row sweeps + sgm_tile_kernel) or sgm_ckpt_kernel (paired form: + 4 pair
     # launches + repeat kernels).  Calls whose last kernel is the fused disparity-only variant
-    # (sgm_tile_kernel<VPL, 2> / sgm_pair_kernel<.., FINAL = 2, ..>) are the ones bench.py times.
+    # (sgm_tile_kernel<VPL, 2> / sgm_tile_h2_kernel<2> / sgm_pair_kernel<.., FINAL = 2, ..>) are the
+    # ones bench.py times.
     def per_step(vpl):
         out = {}
         for name, d, scale in (("FETCH_SIZE", fetch_dir, 2.0), ("WRITE_SIZE", write_dir, 1.0)):
@@ -95,9 +96,12 @@ def main():
                 if cur is None:
                     continue
                 cur["bytes"] += float(r["Counter_Value"]) * 1024.0 * scale
-                if k.startswith("sgm_pair_kernel") or k.startswith("sgm_tile_kernel"):
+                if k.startswith(("sgm_pair_kernel", "sgm_tile_kernel", "sgm_tile_h2_kernel")):
                     args = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")]
-                    final = args[3] if k.startswith("sgm_pair_kernel") and len(args) >= 4 else args[1]
+                    if k.startswith("sgm_tile_h2_kernel"):  # <FINAL> (D = 128)
+                        final = args[0]
+                    else:
+                        final = args[3] if k.startswith("sgm_pair_kernel") and len(args) >= 4 else args[1]
                     if final == "2":
                         cur["fused"] = True
             mine = [g for g in groups if g["vpl"].split("<")[1].split(",")[0].rstrip(">").strip() == str(vpl)]

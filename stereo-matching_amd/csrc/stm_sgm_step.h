@@ -225,6 +225,182 @@ __device__ __forceinline__ void sgm_step_n(const Row<VPL> (&prev)[N], const Row<
   }
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------------------------
+// Two pixels per wave (D = 128): lanes 0-31 hold one pixel's disparities, four per lane, lanes
+// 32-63 another pixel's, and one instruction sequence steps both paths.
+//
+// The kernels that run at D <= 128 are bound by VALU instructions issued (a wave64 instruction
+// holds its SIMD for four cycles whatever it computes).  With two values per lane and one
+// pixel per wave a step is ~21 of them, 8 for the six-stage wave minimum and its broadcast
+// alone; here one sequence of ~27 serves two pixels: the minimum is a five-stage butterfly
+// over 32 lanes that leaves the result in every lane of its half (no v_readlane, no copy
+// back), and the adds come packed.  Same operations on the same operands per pixel -> same
+// bits.
+// ---------------------------------------------------------------------------------
+struct StepCtxH2 {
+  float p1v;           // P1 in a VGPR
+  float below, above;  // lanes 0 / 32 of `below` and 31 / 63 of `above` stay +inf
+  bool drop_tail;      // this lane's last element is d = D-1 and the reference minimum leaves it out (Q5)
+  __device__ __forceinline__ void init(float p1, int hl, int dlim) {
+    p1v = in_vgpr(p1);
+    below = above = in_vgpr(__builtin_inff());
+    drop_tail = hl == 31 && dlim < 128;
+  }
+};
+
+// Minimum over the 32 lanes of the lane's half, in every lane: xor 1, xor 2 (quad
+// permutations), mirror within 8, mirror within 16, then the two rows of a half are exchanged
+// (v_permlane16_swap of two copies: one ends up holding the even rows' values in both rows of
+// a pair, the other the odd rows').  NaNs are ignored unless every lane holds one, as in
+// wave_min_f32.
+__device__ __forceinline__ float half_min_f32(float v) {
+  float t;
+  asm("s_nop 1\n\t"
+      "v_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_mov_b32 %1, %0\n\t"
+      "s_nop 1\n\t"
+      "v_permlane16_swap_b32 %1, %0\n\t"
+      "s_nop 1\n\t"
+      "v_min_f32 %0, %0, %1"
+      : "+v"(v), "=&v"(t));
+  return v;
+}
+
+// The same for integers (the winner's index in the fused winner-takes-all).
+__device__ __forceinline__ int half_min_i32(int v) {
+  int t;
+  asm("s_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_mov_b32 %1, %0\n\t"
+      "s_nop 1\n\t"
+      "v_permlane16_swap_b32 %1, %0\n\t"
+      "s_nop 1\n\t"
+      "v_min_i32 %0, %0, %1"
+      : "+v"(v), "=&v"(t));
+  return v;
+}
+
+// One step for both halves (semiglobal.cpp:129-157).  `pen` holds the penalties P2' of the
+// lane's half, one per lane of each 16-lane row (both rows of a half hold the same sixteen);
+// PEN_LANE selects this step's.
+template <int PEN_LANE>
+__device__ __forceinline__ Row<4> sgm_step_h2(const Row<4> &prev, const Row<4> &c, float pen, StepCtxH2 &X) {
+  static_assert(!kExactNonFinite, "the exact non-finite variant uses sgm_step");
+  const float inf = __builtin_inff();
+  float lm = X.drop_tail ? inf : prev.v[3];
+  lm = vmin_f32(vmin3_f32(lm, prev.v[0], prev.v[1]), prev.v[2]);
+  const float m = half_min_f32(lm);
+  float far;  // m + P2'
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+      : "=v"(far) : "v"(pen), "v"(m), "n"(PEN_LANE));
+  // L(d0-1) + P1 from the lane below, L(d0+4) + P1 from the lane above, inside each half: a
+  // shift inside the 16-lane rows, then the lanes at a row boundary inside a half (16 and 48 /
+  // 15 and 47) by a wave shift restricted to those rows and banks (the other lanes of the
+  // bank receive the value they already hold).  Lanes 0 / 32 and 31 / 63 are never written.
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %2, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %3, %4 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %2, %4 wave_shr:1 row_mask:0xa bank_mask:0x1\n\t"
+      "v_add_f32_dpp %1, %3, %4 wave_shl:1 row_mask:0x5 bank_mask:0x8"
+      : "+v"(X.below), "+v"(X.above) : "v"(prev.v[3]), "v"(prev.v[0]), "v"(X.p1v));
+  const f32x2 p1 = {X.p1v, X.p1v};
+  const f32x2 w01 = f32x2{prev.v[0], prev.v[1]} + p1;
+  const f32x2 w23 = f32x2{prev.v[2], prev.v[3]} + p1;
+  float t[4];
+  t[0] = vmin_f32(vmin3_f32(prev.v[0], X.below, w01.y), far);
+  t[1] = vmin_f32(vmin3_f32(prev.v[1], w01.x, w23.x), far);
+  t[2] = vmin_f32(vmin3_f32(prev.v[2], w01.y, w23.y), far);
+  t[3] = vmin_f32(vmin3_f32(prev.v[3], w23.x, X.above), far);
+  const f32x2 m2 = {m, m};
+  const f32x2 r01 = (f32x2{c.v[0], c.v[1]} + f32x2{t[0], t[1]}) - m2;
+  const f32x2 r23 = (f32x2{c.v[2], c.v[3]} + f32x2{t[2], t[3]}) - m2;
+  Row<4> cur;
+  cur.v[0] = r01.x; cur.v[1] = r01.y; cur.v[2] = r23.x; cur.v[3] = r23.y;
+  return cur;
+}
+
+// Two independent steps of the two-pixel form at once (the forward and the inverse chain of
+// the same lines).  A wave issues in order; a DPP instruction may read a register only two
+// wait states after the VALU write that produced it, and the butterfly minimum is a chain of
+// such reads.  The two chains' cross-lane instructions -- minima, neighbour adds, the P2'
+// broadcast -- are interleaved here so that each one's wait states are the other's
+// instructions: 24 instructions, no padding.  What follows per chain (packed adds, three-way
+// minima) has no cross-lane reads and is left to the compiler's scheduler.
+template <int PEN_F, int PEN_I>
+__device__ __forceinline__ void sgm_step_h2x2(Row<4> &pf, const Row<4> &cf, Row<4> &pi, const Row<4> &ci,
+                                              float pen, StepCtxH2 &XF, StepCtxH2 &XI) {
+  static_assert(!kExactNonFinite, "the exact non-finite variant uses sgm_step");
+  const float inf = __builtin_inff();
+  float mf = XF.drop_tail ? inf : pf.v[3];
+  float mi = XI.drop_tail ? inf : pi.v[3];
+  mf = vmin_f32(vmin3_f32(mf, pf.v[0], pf.v[1]), pf.v[2]);
+  mi = vmin_f32(vmin3_f32(mi, pi.v[0], pi.v[1]), pi.v[2]);
+  float tf, ti, farf, fari;
+#define STM_H2_MIN(reg, ctrl) "v_min_f32_dpp " reg ", " reg ", " reg " " ctrl " row_mask:0xf bank_mask:0xf\n\t"
+  asm("s_nop 1\n\t"
+      STM_H2_MIN("%0", "quad_perm:[1,0,3,2]")
+      STM_H2_MIN("%1", "quad_perm:[1,0,3,2]")
+      "v_add_f32_dpp %6, %10, %15 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      STM_H2_MIN("%0", "quad_perm:[2,3,0,1]")
+      STM_H2_MIN("%1", "quad_perm:[2,3,0,1]")
+      "v_add_f32_dpp %7, %11, %15 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+      STM_H2_MIN("%0", "row_half_mirror")
+      STM_H2_MIN("%1", "row_half_mirror")
+      "v_add_f32_dpp %8, %12, %15 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      STM_H2_MIN("%0", "row_mirror")
+      STM_H2_MIN("%1", "row_mirror")
+      "v_add_f32_dpp %9, %13, %15 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32 %2, %0\n\t"
+      "v_mov_b32 %3, %1\n\t"
+      "v_add_f32_dpp %6, %10, %15 wave_shr:1 row_mask:0xa bank_mask:0x1\n\t"
+      "v_permlane16_swap_b32 %2, %0\n\t"
+      "v_permlane16_swap_b32 %3, %1\n\t"
+      "v_add_f32_dpp %7, %11, %15 wave_shl:1 row_mask:0x5 bank_mask:0x8\n\t"
+      "v_add_f32_dpp %8, %12, %15 wave_shr:1 row_mask:0xa bank_mask:0x1\n\t"
+      "v_min_f32 %0, %0, %2\n\t"
+      "v_min_f32 %1, %1, %3\n\t"
+      "v_add_f32_dpp %9, %13, %15 wave_shl:1 row_mask:0x5 bank_mask:0x8\n\t"
+      "v_add_f32_dpp %4, %14, %0 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %5, %14, %1 row_newbcast:%17 row_mask:0xf bank_mask:0xf"
+      : "+v"(mf), "+v"(mi), "=&v"(tf), "=&v"(ti), "=&v"(farf), "=&v"(fari), "+v"(XF.below), "+v"(XF.above),
+        "+v"(XI.below), "+v"(XI.above)
+      : "v"(pf.v[3]), "v"(pf.v[0]), "v"(pi.v[3]), "v"(pi.v[0]), "v"(pen), "v"(XF.p1v), "n"(PEN_F), "n"(PEN_I));
+#undef STM_H2_MIN
+  auto tail = [](Row<4> &prev, const Row<4> &c, float m, float far, float below, float above, float p1v) {
+    const f32x2 p1 = {p1v, p1v};
+    const f32x2 w01 = f32x2{prev.v[0], prev.v[1]} + p1;
+    const f32x2 w23 = f32x2{prev.v[2], prev.v[3]} + p1;
+    float t[4];
+    t[0] = vmin_f32(vmin3_f32(prev.v[0], below, w01.y), far);
+    t[1] = vmin_f32(vmin3_f32(prev.v[1], w01.x, w23.x), far);
+    t[2] = vmin_f32(vmin3_f32(prev.v[2], w01.y, w23.y), far);
+    t[3] = vmin_f32(vmin3_f32(prev.v[3], w23.x, above), far);
+    const f32x2 m2 = {m, m};
+    const f32x2 r01 = (f32x2{c.v[0], c.v[1]} + f32x2{t[0], t[1]}) - m2;
+    const f32x2 r23 = (f32x2{c.v[2], c.v[3]} + f32x2{t[2], t[3]}) - m2;
+    prev.v[0] = r01.x; prev.v[1] = r01.y; prev.v[2] = r23.x; prev.v[3] = r23.y;
+  };
+  tail(pf, cf, mf, farf, XF.below, XF.above, XF.p1v);
+  tail(pi, ci, mi, fari, XI.below, XI.above, XF.p1v);
+}
+
 // ---------------------------------------------------------------------------------
 // One step with its front half scheduled by hand (whole lanes only; VPL = 2 or 4).
 //

@@ -40,6 +40,7 @@
 #include "stm_sgm_tiled.h"
 
 #include <stdlib.h>
+#include <type_traits>
 
 #include "stm_sgm_step.h"
 
@@ -1309,6 +1310,491 @@ __global__ __launch_bounds__(2 * kT * 64, VPL >= 4 ? 4 : 8) void sgm_tile_kernel
   }
 }
 
+// ---- D = 128: two lines of a pair per wave ---------------------------------------------------
+// sgm_tile_h2_kernel: four waves own a tile (cost + sum tile: 64 KB of LDS, two workgroups per
+// CU) and take it through the four pairs; each wave steps two lines of a pair at once, one
+// per half (sgm_step_h2).  On the diagonal pairs a line is two segments (k+1 and 7-k pixels);
+// a wave's two lines are chosen so that both change segment at the same slot -- line w in the
+// order (first, second) with line 6-w in the order (second, first), w = 0..2; wave 3 takes
+// line 3 (4 + 4) and the main diagonal (8, cut into 4 + 4 that continue) -- which keeps the
+// control flow wave-uniform.  Interior tiles whose inverse passes all count once (or all not
+// at all) take this form; the others (image border, the reference's re-walked diagonals: a
+// few per cent) run the one-line-per-wave forms above, two lines after each other per wave.
+struct H2Part {
+  int ex, ey, n;
+};
+
+template <int PHASE>
+__device__ __forceinline__ void h2_parts(int w, int half, H2Part &p0, H2Part &p1, bool &restart) {
+  constexpr int dx = PhaseDir<PHASE>::dx, dy = PhaseDir<PHASE>::dy;
+  auto part = [](const Seg &s) { H2Part p; p.ex = s.ex; p.ey = s.ey; p.n = s.n; return p; };
+  if (PHASE < 2) {
+    p0 = part(tile_line<PHASE>(2 * w + half, kT, kT));
+    p1.ex = p1.ey = p1.n = 0;
+    restart = false;
+  } else if (w < 3) {
+    const int j = half ? 6 - w : w;
+    p0 = part(tile_line<PHASE>(half ? j + kT : j, kT, kT));
+    p1 = part(tile_line<PHASE>(half ? j : j + kT, kT, kT));
+    restart = true;
+  } else if (!half) {
+    p0 = part(tile_line<PHASE>(3, kT, kT));
+    p1 = part(tile_line<PHASE>(3 + kT, kT, kT));
+    restart = true;
+  } else {
+    p0 = part(tile_line<PHASE>(kT - 1, kT, kT));
+    p0.n = 4;
+    p1.ex = p0.ex + 4 * dx; p1.ey = p0.ey + 4 * dy; p1.n = 4;
+    restart = false;
+  }
+}
+
+__device__ __forceinline__ constexpr int h2_na(int phase, int w) { return phase < 2 ? kT : (w < 3 ? w + 1 : 4); }
+
+// Offset (floats) of the state of direction `dir` after the pixel (rx, ry) relative to a
+// tile's origin, rx, ry in [-1, 8], inside an image's block of row (is_row) or column border
+// states, minus the tile's own term ((trow * W + x0) * D resp. (tcol * H + y0) * D); see
+// border_ptr.
+__device__ __forceinline__ int h2_entry_offset(const TiledGeom &G, int dir, int rx, int ry, bool &is_row) {
+  int k;
+  switch (dir) {
+    case 0: is_row = false; k = 0; break;
+    case 1: is_row = false; k = 3; break;
+    case 2: is_row = true; k = 0; break;
+    case 3: is_row = true; k = 3; break;
+    case 4: is_row = (ry & 7) == 7; k = 1; break;
+    case 5: is_row = (ry & 7) == 0; k = 5; break;
+    case 6: is_row = (ry & 7) == 7; k = is_row ? 2 : 4; break;
+    default: is_row = (ry & 7) == 0; k = is_row ? 4 : 2; break;
+  }
+  if (is_row) return ((k * G.nTR + (ry >> 3)) * G.W + rx) * G.D;
+  return ((k * G.nTC + (rx >> 3)) * G.H + ry) * G.D;
+}
+
+// Per-lane constants of a pair: where the lane's line lies in the tile and where its four
+// entry states lie relative to a tile.
+struct H2Pair {
+  int pix0, pix1;   // tile pixel index (y * 8 + x) of the first slot of either part
+  bool restart;     // the second part begins at an entry state (it is another diagonal)
+  int eoff[4];      // F / I entry of the first part, F / I entry of the second: offset in floats (a
+                    // multiple of D) | 1 when it lies in the row border states
+};
+
+template <int PHASE>
+__device__ __forceinline__ void h2_pair_init(H2Pair &K, const TiledGeom &G, int w, int half) {
+  constexpr int dx = PhaseDir<PHASE>::dx, dy = PhaseDir<PHASE>::dy;
+  H2Part p[2];
+  h2_parts<PHASE>(w, half, p[0], p[1], K.restart);
+  K.pix0 = p[0].ey * kT + p[0].ex;
+  K.pix1 = p[1].ey * kT + p[1].ex;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    bool rf, ri;
+    const int of = h2_entry_offset(G, 2 * PHASE, p[i].ex - dx, p[i].ey - dy, rf);
+    const int oi = h2_entry_offset(G, 2 * PHASE + 1, p[i].ex + p[i].n * dx, p[i].ey + p[i].n * dy, ri);
+    K.eoff[2 * i] = of | (rf ? 1 : 0);
+    K.eoff[2 * i + 1] = oi | (ri ? 1 : 0);
+  }
+}
+
+// A tile's terms of the entry addresses.
+struct H2TileBase {
+  const float *row, *col;
+};
+__device__ __forceinline__ H2TileBase h2_tile_base(float *ws, const TiledGeom &G, const TileWalk &t) {
+  H2TileBase T;
+  T.row = ws + G.rowb_off + (long long)t.b * G.rowb_img + (long long)(t.trow * G.W + t.tcol * kT) * G.D;
+  T.col = ws + G.colb_off + (long long)t.b * G.colb_img + (long long)(t.tcol * G.H + t.trow * kT) * G.D;
+  return T;
+}
+
+template <int N>
+__device__ __forceinline__ void h2_load_entries(Row<4> (&E)[4], const H2Pair &K, const H2TileBase &T, int d0) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const float *p = ((K.eoff[i] & 1) ? T.row : T.col) + (K.eoff[i] & ~1);
+    E[i] = load_row<4, true>(p, 0, 128, d0);
+  }
+}
+
+// How the inverse passes of a pair count inside a tile (seg_counts): 1 = every one once, 0 =
+// none at all (the reference never runs them there), 2 = some once and some not (per line),
+// -1 = the tile holds a diagonal that counts several times or before its forward pass: the
+// generic forms.
+template <int PHASE>
+__device__ __forceinline__ int h2_count_class(const TiledGeom &G, int x0, int y0, int true_paths) {
+  if (PHASE < 2 || true_paths) return 1;
+  const int e = G.W - G.H;
+  if (PHASE == 2) {
+    const int lo = x0 - y0 - (kT - 1), hi = x0 - y0 + (kT - 1);  // x - y over the tile
+    if (e > 0) {
+      if (lo <= e && e <= hi) return -1;
+      if (lo >= 0 && hi <= e - 1) return 0;
+      return (hi < 0 || lo > e) ? 1 : 2;
+    }
+    if (e < -1) {
+      if (lo <= e && e <= hi) return -1;
+      if (lo >= e + 1 && hi <= -1) return 0;
+      return (hi < e || lo >= 0) ? 1 : 2;
+    }
+    return 1;
+  }
+  if (e > 0) {
+    const int lo = x0 + y0, hi = x0 + y0 + 2 * (kT - 1);  // x + y over the tile
+    if (lo <= G.H - 1 && G.H - 1 <= hi) return -1;
+    if (lo >= G.H && hi <= G.W - 1) return 0;
+    return (hi < G.H - 1 || lo > G.W - 1) ? 1 : 2;
+  }
+  return 1;
+}
+
+// Penalties of the lane's line: lane i of every 16-lane row holds the one of slot i & 7 on
+// the F chain (i < 8: the step from its predecessor) or the I chain (from its successor).
+template <int PHASE, int NA>
+__device__ __forceinline__ float h2_penalties(const H2Pair &K, const float *Ip, float p1, float p2, int lane) {
+  constexpr int dx = PhaseDir<PHASE>::dx, dy = PhaseDir<PHASE>::dy;
+  constexpr int pstep = dy * kT + dx;
+  const int s = lane & 7;
+  const bool inv = (lane >> 3) & 1;
+  const int pix = s < NA ? K.pix0 + s * pstep : K.pix1 + (s - NA) * pstep;
+  const int px = pix & (kT - 1), py = pix >> 3;
+  const int qx = px + (inv ? dx : -dx), qy = py + (inv ? dy : -dy);
+  return sgm_penalty(Ip[(py + 1) * (kT + 2) + px + 1], Ip[(qy + 1) * (kT + 2) + qx + 1], p1, p2);
+}
+
+__device__ __forceinline__ Row<4> h2_lds_row(const float *tile, int byte_addr) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f q = *reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(tile) + byte_addr);
+  Row<4> r;
+  r.v[0] = q.x; r.v[1] = q.y; r.v[2] = q.z; r.v[3] = q.w;
+  return r;
+}
+__device__ __forceinline__ void h2_lds_store(float *tile, int byte_addr, const Row<4> &r) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  v4f q;
+  q.x = r.v[0]; q.y = r.v[1]; q.z = r.v[2]; q.w = r.v[3];
+  *reinterpret_cast<v4f *>(reinterpret_cast<char *>(tile) + byte_addr) = q;
+}
+
+template <int S>
+struct H2Slot {};
+
+// One pair of an interior tile for one wave (two lines): both chains, `between` (the barrier
+// behind which the previous pair's update is complete), the update S = (S + F) + I.
+template <int PHASE, int NA, int FINAL, typename Between>
+__device__ __forceinline__ void h2_pair(const H2Pair &K, const Row<4> (&E)[4], int cls, int w, int half, const TiledGeom &G,
+                                        int true_paths, const float *Ct,
+                                        float *St, const float *Ip, float p1, float p2, StepCtxH2 &X, int lane,
+                                        int hl16, int W, int x0, int y0, float *__restrict__ out,
+                                        int32_t *__restrict__ disp, Between between) {
+  constexpr int dx = PhaseDir<PHASE>::dx, dy = PhaseDir<PHASE>::dy;
+  constexpr int pstep = dy * kT + dx;
+  constexpr int kPixBytes = 128 * 4;
+  StepCtxH2 XI = X;  // the inverse chain's cross-lane scratch (its own +inf edge lanes)
+  // cls (h2_count_class): 0 no inverse pass at all, 1 all of them, 2 per line and part
+  const bool run_inv = cls != 0;
+  bool run0 = true, run1 = true;
+  if (PHASE >= 2 && cls == 2) {
+    H2Part q0, q1;
+    bool restart_;
+    h2_parts<PHASE>(w, half, q0, q1, restart_);
+    Seg s0, s1;
+    s0.ex = q0.ex; s0.ey = q0.ey; s0.n = q0.n;
+    s1.ex = q1.ex; s1.ey = q1.ey; s1.n = q1.n;
+    run0 = seg_counts<PHASE>(s0, x0, y0, G, true_paths).inv != 0;
+    run1 = seg_counts<PHASE>(s1, x0, y0, G, true_paths).inv != 0;
+  }
+  const float pen = h2_penalties<PHASE, NA>(K, Ip, p1, p2, lane);
+  const int a0 = K.pix0 * kPixBytes + hl16, a1 = K.pix1 * kPixBytes + hl16;
+  auto addr = [&](auto s_) {  // LDS byte address of slot s (the slot part is an immediate)
+    constexpr int s = decltype(s_)::value;
+    return s < NA ? a0 + s * pstep * kPixBytes : a1 + (s - NA) * pstep * kPixBytes;
+  };
+  Row<4> LF[kT], LI[kT];
+  Row<4> pf = E[0];
+  Row<4> pi = NA < kT ? E[3] : E[1];
+  using std::integral_constant;
+  if (run_inv) {
+    // Slot s of the forward chain together with slot 7 - s of the inverse chain
+    // (sgm_step_h2x2); the cost rows of the next two slots are requested first.
+    Row<4> cf = h2_lds_row(Ct, addr(integral_constant<int, 0>()));
+    Row<4> ci = h2_lds_row(Ct, addr(integral_constant<int, kT - 1>()));
+    auto both = [&](auto s_) {
+      constexpr int s = decltype(s_)::value, r = kT - 1 - s;
+      if constexpr (PHASE >= 2 && s == NA && s > 0) {
+        if (K.restart) pf = E[2];
+      }
+      if constexpr (PHASE >= 2 && r == NA - 1 && r < kT - 1) {
+        if (K.restart) pi = E[1];
+      }
+      Row<4> cfn = cf, cin = ci;
+      if constexpr (s < kT - 1) {
+        cfn = h2_lds_row(Ct, addr(integral_constant<int, s + 1>()));
+        cin = h2_lds_row(Ct, addr(integral_constant<int, r - 1>()));
+      }
+      sgm_step_h2x2<s, 8 + r>(pf, cf, pi, ci, pen, X, XI);
+      LF[s] = pf;
+      LI[r] = pi;
+      cf = cfn;
+      ci = cin;
+    };
+    both(integral_constant<int, 0>()); both(integral_constant<int, 1>());
+    both(integral_constant<int, 2>()); both(integral_constant<int, 3>());
+    both(integral_constant<int, 4>()); both(integral_constant<int, 5>());
+    both(integral_constant<int, 6>()); both(integral_constant<int, 7>());
+  } else {
+    auto fstep = [&](auto s_) {
+      constexpr int s = decltype(s_)::value;
+      if constexpr (PHASE >= 2 && s == NA && s > 0) {
+        if (K.restart) pf = E[2];
+      }
+      const Row<4> c = h2_lds_row(Ct, addr(s_));
+      pf = sgm_step_h2<s>(pf, c, pen, X);
+      LF[s] = pf;
+    };
+    fstep(integral_constant<int, 0>()); fstep(integral_constant<int, 1>());
+    fstep(integral_constant<int, 2>()); fstep(integral_constant<int, 3>());
+    fstep(integral_constant<int, 4>()); fstep(integral_constant<int, 5>());
+    fstep(integral_constant<int, 6>()); fstep(integral_constant<int, 7>());
+  }
+  between();
+  // The update, four slots at a time: their sums are requested together (the compiler cannot
+  // move an LDS read above the previous slot's write -- it does not know that slots never
+  // alias -- and a read's latency per slot would be most of the update).
+  auto update4 = [&](auto base_) {
+    constexpr int s0 = decltype(base_)::value;
+    Row<4> acc[4];
+    int a[4];
+    a[0] = addr(integral_constant<int, s0>());
+    a[1] = addr(integral_constant<int, s0 + 1>());
+    a[2] = addr(integral_constant<int, s0 + 2>());
+    a[3] = addr(integral_constant<int, s0 + 3>());
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (PHASE == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i].v[j] = 0.0f;
+      } else {
+        acc[i] = h2_lds_row(St, a[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int s = s0 + i;
+      f32x2 lo = f32x2{acc[i].v[0], acc[i].v[1]} + f32x2{LF[s].v[0], LF[s].v[1]};
+      f32x2 hi = f32x2{acc[i].v[2], acc[i].v[3]} + f32x2{LF[s].v[2], LF[s].v[3]};
+      if (run_inv) {
+        const f32x2 lo2 = lo + f32x2{LI[s].v[0], LI[s].v[1]};
+        const f32x2 hi2 = hi + f32x2{LI[s].v[2], LI[s].v[3]};
+        const bool r = PHASE < 2 || (s < NA ? run0 : run1);
+        lo = r ? lo2 : lo;
+        hi = r ? hi2 : hi;
+      }
+      acc[i].v[0] = lo.x; acc[i].v[1] = lo.y; acc[i].v[2] = hi.x; acc[i].v[3] = hi.y;
+      if (PHASE < 3) {
+        h2_lds_store(St, a[i], acc[i]);
+      } else {
+        const int pix = s < NA ? K.pix0 + s * pstep : K.pix1 + (s - NA) * pstep;
+        const unsigned q = (unsigned)((y0 + (pix >> 3)) * W + (x0 + (pix & (kT - 1))));  // < H * W
+        const int d0 = hl16 >> 2;
+        if (FINAL != 2) store_row<4, true>(out, (size_t)q, 128, d0, acc[i]);
+        if (FINAL != 0) {
+          // Winner takes all per half (src/winners_take_all.cu:21-40): strict-'<' scan in
+          // register order, then the lowest lane of the half among those holding its minimum;
+          // a NaN at d = 0 wins, as in the reference scan.
+          float best = __builtin_inff();
+          int idx = d0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (acc[i].v[j] < best) { best = acc[i].v[j]; idx = d0 + j; }
+          // ... without leaving the vector unit: the lanes holding the half's minimum offer
+          // their index, the others INT_MAX; a NaN at d = 0 offers -1; minimum over the half.
+          const float m = half_min_f32(best);
+          int key = best == m ? idx : 0x7fffffff;
+          if (hl16 == 0 && acc[i].v[0] != acc[i].v[0]) key = -1;
+          key = half_min_i32(key);
+          const int win = key < 0 ? 0 : key;
+          if ((lane & 31) == 0) disp[q] = win;
+        }
+      }
+    }
+  };
+  update4(integral_constant<int, 0>());
+  update4(integral_constant<int, 4>());
+}
+
+// The pair with the wave's slot count as a constant (the diagonal pairs change segment at
+// slot w + 1, wave 3 at slot 4).
+template <int PHASE, int FINAL, typename Between>
+__device__ __forceinline__ void h2_pair_w(int w, int half, const H2Pair &K, const Row<4> (&E)[4], int cls,
+                                          const TileArgs &P, const float *Ct, float *St, const float *Ip,
+                                          StepCtxH2 &X, int lane, int hl16, int x0, int y0,
+                                          float *__restrict__ out, int32_t *__restrict__ disp, Between between) {
+#define STM_H2_PAIR(NA)                                                                              \
+  h2_pair<PHASE, NA, FINAL>(K, E, cls, w, half, P.G, P.true_paths, Ct, St, Ip, P.p1, P.p2, X, lane, hl16, \
+                            P.G.W, x0, y0, out, disp, between)
+  if constexpr (PHASE < 2) {
+    STM_H2_PAIR(kT);
+  } else {
+    switch (w) {
+      case 0: STM_H2_PAIR(1); break;
+      case 1: STM_H2_PAIR(2); break;
+      case 2: STM_H2_PAIR(3); break;
+      default: STM_H2_PAIR(4); break;
+    }
+  }
+#undef STM_H2_PAIR
+}
+
+// A pair of a tile that does not qualify, for one wave: its two lines after each other in the
+// one-line-per-wave forms (two values per lane).
+template <int PHASE, int FINAL, typename Between>
+__device__ __forceinline__ void h2_pair_generic(int w, int tw, int th, const float *Ct, float *St, const float *Ip,
+                                                const TileArgs &P, const BorderBase &B, int x0, int y0,
+                                                float *__restrict__ out, int32_t *__restrict__ disp, StepCtx &X,
+                                                int lane, Between between) {
+  const int d0 = lane * 2;
+  PhaseGeom g[2];
+  Slots<PHASE> sl[2];
+  Row<2> LF[2][kT], LI[2][kT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    g[i] = tile_geom<PHASE>(2 * w + i, tw, th);
+    Entries<2, PHASE> E;
+    load_entries<2, PHASE>(E, g[i], B, P.G, x0, y0, d0);
+    sl[i].init(g[i]);
+    tile_chains<2, PHASE>(sl[i], E, Ct, Ip, P.p1, P.p2, X, lane, LF[i], LI[i]);
+  }
+  between();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) tile_add<2, PHASE, FINAL>(g[i], sl[i], LF[i], LI[i], St, P, x0, y0, out, disp, lane);
+}
+
+template <int FINAL>
+__global__ __launch_bounds__(4 * 64, 2) void sgm_tile_h2_kernel(const float *__restrict__ cost_all,
+                                                                 const float *__restrict__ image_all,
+                                                                 float *__restrict__ out_all,
+                                                                 int32_t *__restrict__ disp_all,
+                                                                 float *__restrict__ ws, const TileArgs P) {
+  constexpr int D = 128;
+  __shared__ __attribute__((aligned(16))) float Ct[kT * kT * D];
+  __shared__ __attribute__((aligned(16))) float St[kT * kT * D];
+  __shared__ float Ip[(kT + 2) * (kT + 2)];
+  const TiledGeom &G = P.G;
+  const int lane = threadIdx.x & 63;
+  const int w = wave_uniform((int)(threadIdx.x >> 6));
+  const int half = lane >> 5, hl = lane & 31;
+  const int d0 = hl * 4, hl16 = hl * 16;
+  const size_t npix = (size_t)G.H * G.W;
+  const int ntiles = G.batch * G.nTR * G.nTC;  // < 2^31 (shape_ok)
+  const int stride = (int)gridDim.x;
+  StepCtxH2 X;
+  X.init(P.p1, hl, P.dlim);
+  StepCtx X1;  // the generic forms: one pixel per wave, two values per lane
+  X1.init(P.p1, lane * 2, P.dlim, lane == 63 && P.dlim < D);
+  H2Pair K0, K1, K2, K3;
+  h2_pair_init<0>(K0, G, w, half);
+  h2_pair_init<1>(K1, G, w, half);
+  h2_pair_init<2>(K2, G, w, half);
+  h2_pair_init<3>(K3, G, w, half);
+  TileWalk cur_t, next_t;  // the tile being computed / the one being prefetched
+  cur_t.init((int)blockIdx.x, stride, G);
+  next_t = cur_t;
+
+  // A tile is interior when all of its neighbours exist (every line enters from a border state).
+  auto interior = [&](const TileWalk &t) {
+    return t.trow >= 1 && t.trow <= G.nTR - 2 && t.tcol >= 1 && t.tcol <= G.nTC - 2 &&
+           (t.trow + 1) * kT <= G.H && (t.tcol + 1) * kT <= G.W;
+  };
+  Row<4> cpre[kT];  // next tile: tile row 2 w + half of the cost tile
+  float ipre = 0.0f;
+  Row<4> E0[4], E1[4];  // next tile: entry states of pairs 0 and 1 (interior tiles)
+  // Every prefetch redefines all of its registers unconditionally (past the last tile it
+  // re-reads that tile; rows and samples outside a partial tile are clamped into it; the
+  // entry states of a tile that is not interior are read at the workspace's first border row).
+  auto prefetch_cost = [&](const TileWalk &t) {
+    const int x0 = t.tcol * kT, y0 = t.trow * kT;
+    const int tw = imin(kT, G.W - x0), th = imin(kT, G.H - y0);
+    const float *cost = cost_all + (size_t)t.b * npix * D;
+    const unsigned rowbase = (unsigned)((y0 + imin(2 * w + half, th - 1)) * G.W + x0);
+#pragma unroll
+    for (int c = 0; c < kT; ++c)
+      cpre[c] = load_row_at<4, true>(cost, (long)((rowbase + (unsigned)imin(c, tw - 1)) * (unsigned)D), D, d0);
+    const int e = imin((int)threadIdx.x, (kT + 2) * (kT + 2) - 1);
+    const int r = e / (kT + 2) - 1, c = e % (kT + 2) - 1;
+    const int gy = imin(y0 + r > 0 ? y0 + r : 0, G.H - 1), gx = imin(x0 + c > 0 ? x0 + c : 0, G.W - 1);
+    ipre = image_all[(size_t)t.b * npix + (unsigned)(gy * G.W + gx)];
+  };
+  auto entry_base = [&](const TileWalk &t) {
+    H2TileBase T = h2_tile_base(ws, G, t);
+    if (!interior(t)) {  // valid dummy addresses: this image's first border row, far enough in
+      T.row = ws + G.rowb_off + (long long)t.b * G.rowb_img + (long long)(G.W + kT) * D;
+      T.col = T.row;
+    }
+    return T;
+  };
+  prefetch_cost(next_t);
+  h2_load_entries<2>(E0, K0, entry_base(next_t), d0);
+  h2_load_entries<2>(E1, K1, entry_base(next_t), d0);
+  for (int id = (int)blockIdx.x; id < ntiles; id += stride) {
+    const int b = cur_t.b, x0 = cur_t.tcol * kT, y0 = cur_t.trow * kT;
+    const int tw = imin(kT, G.W - x0), th = imin(kT, G.H - y0);
+    float *out = out_all ? out_all + (size_t)b * npix * D : nullptr;
+    int32_t *disp = disp_all ? disp_all + (size_t)b * npix : nullptr;
+#ifdef STM_TILE_STAMPS
+    const int tile = id < 4096 ? id : 4096;
+    const int w16 = w;
+#endif
+    STM_STAMP(0);
+    const int cls2 = h2_count_class<2>(G, x0, y0, P.true_paths), cls3 = h2_count_class<3>(G, x0, y0, P.true_paths);
+    const bool fast = interior(cur_t) && cls2 >= 0 && cls3 >= 0;
+    if (2 * w + half < th) {
+#pragma unroll
+      for (int c = 0; c < kT; ++c) h2_lds_store(Ct, ((2 * w + half) * kT + c) * D * 4 + hl16, cpre[c]);
+    }
+    if (threadIdx.x < (kT + 2) * (kT + 2)) Ip[threadIdx.x] = ipre;
+    Row<4> Ea[4], Eb[4];
+    Ea[0] = E0[0]; Ea[1] = E0[1];
+    Eb[0] = E1[0]; Eb[1] = E1[1];
+    STM_STAMP(1);
+    lds_barrier();
+    STM_STAMP(2);
+    if (id + stride < ntiles) next_t.next(G);
+    // A global load takes several times as long as a pair (2-4 us against ~1 us), and results
+    // return in issue order: the entry states of pairs 2 and 3 are requested now, then the next
+    // tile's cost rows; the next tile's pairs 0 and 1 follow once pairs 0 and 1 are done.
+    if (fast) {
+      const H2TileBase T = h2_tile_base(ws, G, cur_t);
+      Row<4> Ec[4], Ed[4];
+      h2_load_entries<4>(Ec, K2, T, d0);
+      h2_load_entries<4>(Ed, K3, T, d0);
+      prefetch_cost(next_t);
+      h2_pair_w<0, FINAL>(w, half, K0, Ea, 1, P, Ct, St, Ip, X, lane, hl16, x0, y0, out, disp, [] {});
+      h2_pair_w<1, FINAL>(w, half, K1, Eb, 1, P, Ct, St, Ip, X, lane, hl16, x0, y0, out, disp, [] { lds_barrier(); });
+      h2_load_entries<2>(E0, K0, entry_base(next_t), d0);
+      h2_load_entries<2>(E1, K1, entry_base(next_t), d0);
+      h2_pair_w<2, FINAL>(w, half, K2, Ec, cls2, P, Ct, St, Ip, X, lane, hl16, x0, y0, out, disp,
+                          [] { lds_barrier(); });
+      STM_STAMP(3);
+      h2_pair_w<3, FINAL>(w, half, K3, Ed, cls3, P, Ct, St, Ip, X, lane, hl16, x0, y0, out, disp,
+                          [&] { STM_STAMP(4); lds_barrier(); STM_STAMP(5); });
+      STM_STAMP(6);
+    } else {
+      prefetch_cost(next_t);
+      const BorderBase B = border_base(ws, G, b);
+      h2_pair_generic<0, FINAL>(w, tw, th, Ct, St, Ip, P, B, x0, y0, out, disp, X1, lane, [] {});
+      h2_pair_generic<1, FINAL>(w, tw, th, Ct, St, Ip, P, B, x0, y0, out, disp, X1, lane, [] { lds_barrier(); });
+      h2_load_entries<2>(E0, K0, entry_base(next_t), d0);
+      h2_load_entries<2>(E1, K1, entry_base(next_t), d0);
+      h2_pair_generic<2, FINAL>(w, tw, th, Ct, St, Ip, P, B, x0, y0, out, disp, X1, lane, [] { lds_barrier(); });
+      h2_pair_generic<3, FINAL>(w, tw, th, Ct, St, Ip, P, B, x0, y0, out, disp, X1, lane, [] { lds_barrier(); });
+    }
+    cur_t = next_t;
+    lds_barrier();
+    STM_STAMP(7);
+  }
+}
+
 // ---- host side ------------------------------------------------------------------------
 #ifdef STM_TILE_STAMPS
 unsigned long long *g_tile_stamps = nullptr;
@@ -1405,17 +1891,39 @@ int run_tiled(const float *cost, const float *left, float *out, int32_t *disp, c
 #ifdef STM_TILE_STAMPS
     A.stamps = g_tile_stamps;
 #endif
-    // Persistent workgroups, one per CU (the LDS allows no more); tiles are dealt round robin.
+    // Persistent workgroups; tiles are dealt round robin.
     const long long ntiles = (long long)G.nTR * G.nTC * batch;
-    // (two per CU where the tile's LDS footprint allows it: D <= 128)
-    const long long wgs = (long long)device_cus() * (VPL >= 4 ? 1 : 2);
-    const dim3 grid((unsigned)(ntiles < wgs ? ntiles : wgs)), block(2 * kT * 64);
-    if (final_mode == 0)
-      hipLaunchKernelGGL((sgm_tile_kernel<VPL, 0>), grid, block, 0, s, cost, left, out, disp, ws, A);
-    else if (final_mode == 1)
-      hipLaunchKernelGGL((sgm_tile_kernel<VPL, 1>), grid, block, 0, s, cost, left, out, disp, ws, A);
-    else
-      hipLaunchKernelGGL((sgm_tile_kernel<VPL, 2>), grid, block, 0, s, cost, left, out, disp, ws, A);
+    if constexpr (VPL == 2) {
+      // D = 128: four-wave workgroups, two lines of a pair per wave, two workgroups per CU
+      const long long wgs = (long long)device_cus() * 2;
+      const dim3 grid((unsigned)(ntiles < wgs ? ntiles : wgs)), block(4 * 64);
+      if (final_mode == 0)
+        hipLaunchKernelGGL((sgm_tile_h2_kernel<0>), grid, block, 0, s, cost, left, out, disp, ws, A);
+      else if (final_mode == 1)
+        hipLaunchKernelGGL((sgm_tile_h2_kernel<1>), grid, block, 0, s, cost, left, out, disp, ws, A);
+      else
+        hipLaunchKernelGGL((sgm_tile_h2_kernel<2>), grid, block, 0, s, cost, left, out, disp, ws, A);
+    } else if constexpr (VPL >= 4) {
+      // D = 256: one sixteen-wave workgroup per CU (the LDS allows no more)
+      const long long wgs = device_cus();
+      const dim3 grid((unsigned)(ntiles < wgs ? ntiles : wgs)), block(2 * kT * 64);
+      if (final_mode == 0)
+        hipLaunchKernelGGL((sgm_tile_kernel<VPL, 0>), grid, block, 0, s, cost, left, out, disp, ws, A);
+      else if (final_mode == 1)
+        hipLaunchKernelGGL((sgm_tile_kernel<VPL, 1>), grid, block, 0, s, cost, left, out, disp, ws, A);
+      else
+        hipLaunchKernelGGL((sgm_tile_kernel<VPL, 2>), grid, block, 0, s, cost, left, out, disp, ws, A);
+    } else {
+      // D = 64: sixteen-wave workgroups, two per CU
+      const long long wgs = (long long)device_cus() * 2;
+      const dim3 grid((unsigned)(ntiles < wgs ? ntiles : wgs)), block(2 * kT * 64);
+      if (final_mode == 0)
+        hipLaunchKernelGGL((sgm_tile_kernel<VPL, 0>), grid, block, 0, s, cost, left, out, disp, ws, A);
+      else if (final_mode == 1)
+        hipLaunchKernelGGL((sgm_tile_kernel<VPL, 1>), grid, block, 0, s, cost, left, out, disp, ws, A);
+      else
+        hipLaunchKernelGGL((sgm_tile_kernel<VPL, 2>), grid, block, 0, s, cost, left, out, disp, ws, A);
+    }
     return check_launch("stm_sgm_f32 (tiled: tiles)");
   }
 }

@@ -25,4 +25,5 @@ fi
 if [ "$1" = "usage" ]; then
   /opt/rocm/bin/hipcc $FL --cuda-device-only -S $C/stm_sgm_tiled.hip -o /tmp/isa/tiled.s -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "Function Name|VGPRs:|Spill|Scratch" | sed 's/.*remark: *//; s/ \[-Rpass.*//' | paste - - - - - | sed 's/_ZN3stm12_GLOBAL__N_1//; s/EvPKfS3.*E\t/\t/' | grep -E "ILi[24]E"
 fi
+cp $ROOT/stereo-matching_amd/stereomatch/libstereomatch_hip.so $ROOT/tools/_probe/libstm_prod.so  # for tools/time_libs.sh
 ls -la $ROOT/stereo-matching_amd/stereomatch/libstereomatch_hip.so $ROOT/tools/_probe/libstm_stamps.so | awk '{print $6,$7,$8,$9}'

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs the fused aggregation of a given build of the library (for rocprofv3 kernel stats of
-diagnostic / probe builds).  python tools/run_lib.py <lib.so> H W D B [tiled|paired]"""
+diagnostic / probe builds).  python tools/run_lib.py <lib.so> H W D B [tiled|paired] [extra flags]"""
 import ctypes
 import os
 import sys
@@ -17,6 +17,8 @@ for name, (restype, argtypes) in _native.PROTOTYPES.items():
     fn.restype, fn.argtypes = restype, argtypes
 H, W, D, B = [int(a) for a in sys.argv[2:6]]
 flags = _native.STM_SGM_FORMS[sys.argv[6] if len(sys.argv) > 6 else "tiled"]
+if len(sys.argv) > 7:
+    flags |= int(sys.argv[7])
 dev = torch.device("cuda:0")
 g = torch.Generator(device="cpu").manual_seed(1)
 cost = (torch.rand((B, H, W, D), generator=g) * 50).to(dev)

@@ -51,6 +51,26 @@ def main():
     st = st[:ntiles]
     t0 = st[:, :, 0].min(axis=1, keepdims=True)
     rel = st - t0[:, :, None]
+    if D == 128:  # sgm_tile_h2_kernel: four waves, all alike
+        names = ["C stored to LDS", "barrier", "loads issued + pairs 0, 1, 2", "pair 3 chains", "barrier (pair 3)",
+                 "pair 3 update, result, winner", "end barrier"]
+        r = rel[:, 0:4, :]
+        ok = (st[:, 0:4, 7] > 0).all(axis=1)  # tiles on the stamped (fast) path
+        r = r[ok]
+        print("stamped tiles: %d of %d" % (ok.sum(), ntiles))
+        print("stamp medians %s" % np.median(r, axis=(0, 1)).astype(int).tolist())
+        med = np.median(np.diff(r, axis=2), axis=(0, 1))
+        for k, nm in enumerate(names):
+            print("   %-40s %8d" % (nm, med[k]))
+        s0 = np.sort(st[ok][:, 0, 0])
+        # the same workgroup's consecutive tiles are `grid` ids apart: estimate the period from
+        # stamps of ids id and id + grid when both are in range
+        grid = int(os.environ.get("STM_GRID", "512"))
+        per = [st[i + grid, 0, 0] - st[i, 0, 0] for i in range(0, ntiles - grid) if ok[i] and ok[i + grid]]
+        if per:
+            print("tile period of a workgroup: median %d ticks (pair 3 + end barrier = period - %d)"
+                  % (np.median(per), np.median(r[:, :, 7])))
+        return
     for grp, names in ((0, NAMES0), (1, NAMES1)):
         r = rel[:, grp * 8:(grp + 1) * 8, :]
         print("group %d: stamp medians %s" % (grp, np.median(r, axis=(0, 1)).astype(int).tolist()))
