@@ -201,12 +201,21 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
   constexpr int PPI = 64 / LP;       // pieces per cooperative load instruction
   constexpr int LD = O + 1;          // padded LDS row: conflict-free ds_read_b32 by 64 lanes
   __shared__ float tile[2][64 * LD];
-  // Path bytes of the column each lane is working on (P bytes = P/4 dwords, padded): a
-  // column's record leaves as whole lines once it is complete (see the end of the loop).
-  constexpr int PB = P / 4 + 4;
+  // Path bytes of the column each lane is working on, collected until a 64-byte run of the
+  // column's record is complete (FL blocks of O bytes; the whole column for O >= 32), which
+  // then leaves in one piece (see the end of the loop).  Keeping whole columns here (16 KB at
+  // D = 256) made the LDS the limit on resident workgroups: four per CU; with runs it is
+  // nine, which is what the kernel's throughput on a batch follows.
+  constexpr int FL = O <= 16 ? 64 / O : 16;  // blocks per run
+  constexpr int PB = FL * LP + (FL == 16 ? 4 : 1);
   __shared__ __attribute__((aligned(16))) unsigned pbuf[64 * PB];
-  __shared__ float init[4][P];
-  __shared__ float fin[4][P + 1];
+  // Column 0's initial costs (read in blocks 0-15) and the last column's final costs (written
+  // from block W - 1 on) share their storage: the host takes this kernel only for W >= 17.  The
+  // 4 KB this saves at D = 256 is what lets five workgroups instead of four share a CU's LDS
+  // (30 of 160 KB each) -- the kernel's throughput at batch size is set by that number.
+  __shared__ float initfin[4][P + 1];
+  float (&init)[4][P + 1] = initfin;
+  float (&fin)[4][P + 1] = initfin;
   const int lane = threadIdx.x;
   const int rq = lane >> 4, v = lane & 15;
   const int b = blockIdx.y;
@@ -341,24 +350,27 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
     // Path directions.  A lane's O bytes of this block are one short piece of a column that
     // lies 4*D bytes away from its neighbours', so storing them directly costs 64 cache lines
     // per instruction (measured: more than half of the kernel at D = 128).  Instead they are
-    // collected per column in LDS; in every block exactly four columns (one per image row of
-    // the wave, those of lane (blk + 1) & 15) receive their last piece, and their 4 x P bytes
-    // leave in one instruction, 16 lanes x O bytes per column.
+    // collected per column in LDS, FL blocks at a time (a 64-byte run of the column's record;
+    // the whole column for O >= 32); in every block 16 / FL lanes per image row complete a run,
+    // and those 4 x 16 / FL runs leave in one instruction, FL lanes x O bytes each.
     {
-      unsigned *mine = &pbuf[lane * PB + (q & 15) * LP];
+      unsigned *mine = &pbuf[lane * PB + (q & (FL - 1)) * LP];
 #pragma unroll
       for (int u = 0; u < LP; ++u) mine[u] = pk[u];
-      wave_lds_handoff();  // the finishing columns' records are read by other lanes
-      const int vd = (blk + 1) & 15;           // lanes finishing a column in this block
-      const int qd = blk - vd;                 // = 15 (mod 16)
-      const int cd = vd + 16 * (qd >> 4);      // that column (negative before the first one)
-      const int crow = blockIdx.x * 4 + rq;    // this lane serves image row rq, piece v
-      const unsigned *src = &pbuf[(rq * 16 + vd) * PB + v * LP];
+      wave_lds_handoff();  // the finishing runs are read by other lanes
+      // Lanes finishing a run in this block: those with (blk - lane) % FL == FL - 1, 16 / FL per
+      // image row; lane v serves the (v / FL)-th of them, piece v % FL of its run.
+      const int vd = ((blk + 1) & (FL - 1)) + FL * (v / FL);
+      const int qd = blk - vd;                 // = FL - 1 (mod FL)
+      const int cd = vd + 16 * (qd >> 4);      // that lane's column (negative before the first one)
+      const int chunk = (qd & 15) - (FL - 1) + (v % FL);  // the piece's O disparities
+      const int crow = blockIdx.x * 4 + rq;    // this lane serves image row rq
+      const unsigned *src = &pbuf[(rq * 16 + vd) * PB + (v % FL) * LP];
       unsigned out_w[LP];
 #pragma unroll
       for (int u = 0; u < LP; ++u) out_w[u] = src[u];
-      if (qd >= 0 && cd < W && crow < H && v * O < D) {
-        int8_t *dst = path + ((size_t)crow * W + cd) * D + v * O;
+      if (qd >= 0 && cd < W && crow < H && chunk * O < D) {
+        int8_t *dst = path + ((size_t)crow * W + cd) * D + chunk * O;
 #pragma unroll
         for (int u = 0; u < LP; u += 4) {
           if (LP >= 4) {
@@ -480,11 +492,12 @@ extern "C" int stm_dp_f32(const float *volume, int8_t *path, float *row_final, i
   const uintptr_t align = VPL >= 4 ? 15 : (VPL == 2 ? 7 : 3);
   const bool vec = (D == VPL * 64) && ((reinterpret_cast<uintptr_t>(volume) & align) == 0) &&
                    ((reinterpret_cast<uintptr_t>(path) & 3) == 0);
-  // Wavefront form: whole O-disparity chunks (O = 8, 16, 32, 64 for D <= 128, 256, 512, 1024)
-  // and 16-byte-aligned cost rows; everything else takes the fixed-point form.
+  // Wavefront form: whole O-disparity chunks (O = 8, 16, 32, 64 for D <= 128, 256, 512, 1024),
+  // 16-byte-aligned cost rows and at least 17 columns (dp_tile_kernel's shared initial / final
+  // cost buffer); everything else takes the fixed-point form.
   int O = 8;
   while (16 * O < D) O <<= 1;
-  const bool wavefront = (D % O == 0) && ((reinterpret_cast<uintptr_t>(volume) & 15) == 0) &&
+  const bool wavefront = (D % O == 0) && W >= 17 && ((reinterpret_cast<uintptr_t>(volume) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(path) & 15) == 0);
   if (wavefront) {
     const dim3 wgrid((H + 3) / 4, batch), wblock(64);

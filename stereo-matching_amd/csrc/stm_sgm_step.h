@@ -401,6 +401,75 @@ __device__ __forceinline__ void sgm_step_h2x2(Row<4> &pf, const Row<4> &cf, Row<
   tail(pi, ci, mi, fari, XI.below, XI.above, XF.p1v);
 }
 
+// Three independent steps of the two-pixel form at once (the three directions of a row sweep):
+// as sgm_step_h2x2, 36 cross-lane instructions without padding.
+template <int PEN0, int PEN1, int PEN2>
+__device__ __forceinline__ void sgm_step_h2x3(Row<4> (&p)[3], const Row<4> (&c)[3], float pen, float p1v,
+                                              float (&below)[3], float (&above)[3], bool drop_tail) {
+  static_assert(!kExactNonFinite, "the exact non-finite variant uses sgm_step");
+  const float inf = __builtin_inff();
+  float m[3], t[3], far[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    m[k] = drop_tail ? inf : p[k].v[3];
+    m[k] = vmin_f32(vmin3_f32(m[k], p[k].v[0], p[k].v[1]), p[k].v[2]);
+  }
+#define STM_H2_MIN3(ctrl)                                                              \
+  "v_min_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                    \
+  "v_min_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                    \
+  "v_min_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf\n\t"
+  asm("s_nop 1\n\t"
+      STM_H2_MIN3("quad_perm:[1,0,3,2]")
+      STM_H2_MIN3("quad_perm:[2,3,0,1]")
+      STM_H2_MIN3("row_half_mirror")
+      STM_H2_MIN3("row_mirror")
+      "v_add_f32_dpp %9, %15, %22 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %10, %16, %22 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %11, %17, %22 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %12, %18, %22 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %13, %19, %22 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %14, %20, %22 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32 %3, %0\n\t"
+      "v_mov_b32 %4, %1\n\t"
+      "v_mov_b32 %5, %2\n\t"
+      "v_add_f32_dpp %9, %15, %22 wave_shr:1 row_mask:0xa bank_mask:0x1\n\t"
+      "v_add_f32_dpp %10, %16, %22 wave_shr:1 row_mask:0xa bank_mask:0x1\n\t"
+      "v_add_f32_dpp %11, %17, %22 wave_shr:1 row_mask:0xa bank_mask:0x1\n\t"
+      "v_permlane16_swap_b32 %3, %0\n\t"
+      "v_permlane16_swap_b32 %4, %1\n\t"
+      "v_permlane16_swap_b32 %5, %2\n\t"
+      "v_add_f32_dpp %12, %18, %22 wave_shl:1 row_mask:0x5 bank_mask:0x8\n\t"
+      "v_add_f32_dpp %13, %19, %22 wave_shl:1 row_mask:0x5 bank_mask:0x8\n\t"
+      "v_add_f32_dpp %14, %20, %22 wave_shl:1 row_mask:0x5 bank_mask:0x8\n\t"
+      "v_min_f32 %0, %0, %3\n\t"
+      "v_min_f32 %1, %1, %4\n\t"
+      "v_min_f32 %2, %2, %5\n\t"
+      "v_add_f32_dpp %6, %21, %0 row_newbcast:%23 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %7, %21, %1 row_newbcast:%24 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %8, %21, %2 row_newbcast:%25 row_mask:0xf bank_mask:0xf"
+      : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(far[0]), "=&v"(far[1]),
+        "=&v"(far[2]), "+v"(below[0]), "+v"(below[1]), "+v"(below[2]), "+v"(above[0]), "+v"(above[1]),
+        "+v"(above[2])
+      : "v"(p[0].v[3]), "v"(p[1].v[3]), "v"(p[2].v[3]), "v"(p[0].v[0]), "v"(p[1].v[0]), "v"(p[2].v[0]), "v"(pen),
+        "v"(p1v), "n"(PEN0), "n"(PEN1), "n"(PEN2));
+#undef STM_H2_MIN3
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const f32x2 p1 = {p1v, p1v};
+    const f32x2 w01 = f32x2{p[k].v[0], p[k].v[1]} + p1;
+    const f32x2 w23 = f32x2{p[k].v[2], p[k].v[3]} + p1;
+    float u[4];
+    u[0] = vmin_f32(vmin3_f32(p[k].v[0], below[k], w01.y), far[k]);
+    u[1] = vmin_f32(vmin3_f32(p[k].v[1], w01.x, w23.x), far[k]);
+    u[2] = vmin_f32(vmin3_f32(p[k].v[2], w01.y, w23.y), far[k]);
+    u[3] = vmin_f32(vmin3_f32(p[k].v[3], w23.x, above[k]), far[k]);
+    const f32x2 m2 = {m[k], m[k]};
+    const f32x2 r01 = (f32x2{c[k].v[0], c[k].v[1]} + f32x2{u[0], u[1]}) - m2;
+    const f32x2 r23 = (f32x2{c[k].v[2], c[k].v[3]} + f32x2{u[2], u[3]}) - m2;
+    p[k].v[0] = r01.x; p[k].v[1] = r01.y; p[k].v[2] = r23.x; p[k].v[3] = r23.y;
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // One step with its front half scheduled by hand (whole lanes only; VPL = 2 or 4).
 //

@@ -227,7 +227,11 @@ __global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float
   constexpr int PF = 2;  // cost rows in flight beyond the current one
   constexpr int NW = kSweepWaves;
   constexpr int D = 64 * VPL;
-  __shared__ __attribute__((aligned(16))) float xch[2][2][NW][D];  // [parity][A/B][wave][d]
+  // At D = 128 the interior waves step two columns per half-wave (sgm_step_h2x3): the unit of
+  // the exchange is then the half-wave, and the other waves follow that numbering.
+  constexpr bool H2 = VPL == 2;
+  constexpr int NV = H2 ? 2 * NW : NW;
+  __shared__ __attribute__((aligned(16))) float xch[2][2][NV][D];  // [parity][A/B][wave or half-wave][d]
   const TiledGeom &G = P.G;
   const int lane = threadIdx.x & 63;
   const int wv = wave_uniform((int)(threadIdx.x >> 6));
@@ -253,6 +257,9 @@ __global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float
   const u64 *subA = (has_left && !left_lds) ? mbox_ptr(ws, G, sweep, b, s - 1, 0) : nullptr;
   const u64 *subB = (has_right && !right_lds) ? mbox_ptr(ws, G, sweep, b, s + 1, 1) : nullptr;
   bool dead = false;
+  // Exchange slots: where this wave's leaving A / B go and where its arriving ones come from.
+  const int slot_pubA = H2 ? 2 * wv + 1 : wv, slot_pubB = H2 ? 2 * wv : wv;
+  const int slot_subA = H2 ? 2 * wv - 1 : wv - 1, slot_subB = H2 ? 2 * wv + 2 : wv + 1;
 
   // Element offsets (32-bit, wave-uniform) of this wave's columns in row 0; a wave at the right
   // border may own fewer than CW columns and re-reads its last one for the others.
@@ -287,6 +294,7 @@ __global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float
   Row<VPL> cb[PF + 1][CW];
   float ic[PF + 1], ip[PF + 1];
   Granules<VPL> qa, qb;
+  Granules<4> qa4;  // (the half-wave form's: four disparities per lane, one mailbox per wave)
 
   // The common case gets a loop of its own: every column of the wave inside the image and none
   // of them in image column 0 or W-1, so no path starts here and nothing is clipped.  At
@@ -294,7 +302,138 @@ __global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float
   // generic loop below), and what that loop spends on start / validity selects and on
   // recomputing 64-bit addresses every row is row time; at D = 256 the sweep is HBM-bound and
   // the two loops take the same time.
-  if (VPL <= 2 && xa >= 1 && xa + CW <= W - 1) {
+  if constexpr (H2) {
+    if (xa >= 1 && xa + CW <= W - 1) {
+      static_assert(!H2 || CW == 4, "two columns per half-wave");
+      // ---- D = 128, interior wave: lanes 0-31 own columns xa, xa + 1, lanes 32-63 columns
+      // xa + 2, xa + 3, four disparities per lane; a row is two batches of three steps.
+      const int half = lane >> 5, hl = lane & 31, dh = hl * 4;
+      const int vw = 2 * wv + half;
+      constexpr int PFH = 1;  // cost rows in flight beyond the current one (registers)
+      // Addresses are a wave-uniform base plus this lane's 32-bit offset (its half's first
+      // column and its disparities).
+      const unsigned loff = (unsigned)(half * 2 * D + dh);
+      const long row_step = (long)(UP ? -1 : 1) * W * D;
+      const float *cnext = cost + (size_t)(UP ? H - 1 : 0) * W * D + (size_t)xa * D;  // next row to fetch
+      int t_next = 0;
+      // Penalties: lane i of every 16-lane row serves column i / 3 (0, 1) of the row's half and
+      // direction i % 3 (0 V, 1 A, 2 B).
+      const int i16 = lane & 15;
+      const int pxh = xa + 2 * half + imin(i16 / 3, 1), pkh = i16 % 3;
+      const int pxsh = pkh == 1 ? pxh - 1 : (pkh == 2 ? pxh + 1 : pxh);
+      const float *inext = image + (size_t)(UP ? H - 1 : 0) * W;
+      const int istep = UP ? -W : W;
+      Row<4> Vh[2], Ah[2], Bh[2], ch[PFH + 1][2];
+      float ich[PFH + 1], iph[PFH + 1];
+      auto refill = [&](Row<4> (&dst)[2], float &icur, float &iprev) {
+        icur = inext[(unsigned)pxh];
+        iprev = (t_next > 0 ? inext - istep : inext)[(unsigned)pxsh];
+        dst[0] = load_row<4, true, true>(cnext + loff, 0, D, 0);
+        dst[1] = load_row<4, true, true>(cnext + (loff + (unsigned)D), 0, D, 0);
+        if (t_next < H - 1) { cnext += row_step; inext += istep; }
+        ++t_next;
+      };
+      const bool colA_here = (xa & (kT - 1)) == 4, colB_here = (xa & (kT - 1)) == 0;  // x % 8 == 7 is xa + 3, == 0 is xa
+      const int y_first = UP ? H - 1 : 0;
+      float *colA = colA_here ? colb_ptr(ws, G, b, UP ? 2 : 1, (xa + 3) >> 3, y_first) : nullptr;
+      float *colB = colB_here ? colb_ptr(ws, G, b, UP ? 5 : 4, xa >> 3, y_first) : nullptr;
+      const int col_step = UP ? -D : D;
+      float *rowV = rowb_ptr(ws, G, b, UP ? 3 : 0, 0, xa);
+      const long long kstride = (long long)G.nTR * W * D;
+      const float p1v = in_vgpr(P.p1);
+      float below[3], above[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) below[k] = above[k] = in_vgpr(__builtin_inff());
+      const bool drop_tail = hl == 31 && P.dlim < D;
+      // LDS exchange, in floats from xch[0][0][0][0]: own slots and the neighbours'.
+      float *xbase = &xch[0][0][0][0];
+      constexpr int kAB = NV * D, kPar = 2 * NV * D;  // from A to B, from parity 0 to 1
+      const unsigned my_off = (unsigned)(vw * D + dh);
+      const unsigned inA_off = (unsigned)((vw > 0 ? vw - 1 : 0) * D + dh);
+      const unsigned inB_off = (unsigned)(kAB + (vw < NV - 1 ? vw + 1 : NV - 1) * D + dh);
+      // A wave at a strip edge reads one mailbox: A from the left (wave 0) or B from the right
+      // (last wave); both only in a one-wave strip, which the sweeps never have.
+      const u64 *sub = !left_lds ? subA : (!right_lds ? subB : nullptr);
+      auto leave = [&](int par, unsigned t) {  // what leaves the half: A of its last column, B of its first
+        if (pubA && half == 1) mbox_publish<4>(pubA, D, dh, t, Ah[1]);
+        if (pubB && half == 0) mbox_publish<4>(pubB, D, dh, t, Bh[0]);
+        store_row<4, true>(xbase + par * kPar + my_off, 0, D, 0, Ah[1]);
+        store_row<4, true>(xbase + par * kPar + kAB + my_off, 0, D, 0, Bh[0]);
+      };
+
+#pragma unroll
+      for (int u = 0; u <= PFH; ++u) refill(ch[u], ich[u], iph[u]);
+      int y = y_first;
+      for (int t0 = 0; t0 < H; t0 += PFH + 1) {
+#pragma unroll
+        for (int u = 0; u <= PFH; ++u) {
+          const int t = t0 + u;
+          if (t < H) {
+            const int par = t & 1;
+            const float pen = sgm_penalty(ich[u], iph[u], P.p1, P.p2);
+            if (t == 0) {
+#pragma unroll
+              for (int j = 0; j < 2; ++j) { Vh[j] = ch[u][j]; Ah[j] = ch[u][j]; Bh[j] = ch[u][j]; }
+              leave(par, 0u);
+            } else {
+              {  // V in column 0, A into column 1 (from column 0), B into column 0 (from column 1)
+                Row<4> st[3] = {Vh[0], Ah[0], Bh[1]};
+                const Row<4> cc[3] = {ch[u][0], ch[u][1], ch[u][0]};
+                sgm_step_h2x3<0, 4, 2>(st, cc, pen, p1v, below, above, drop_tail);
+                Vh[0] = st[0];
+                Ah[1] = st[1];
+                Bh[0] = st[2];
+              }
+              leave(par, (unsigned)t);
+              {  // V in column 1, A into column 0 and B into column 1 from what arrived
+                Row<4> st[3];
+                st[0] = Vh[1];
+                st[1] = load_row<4, true>(xbase + (par ^ 1) * kPar + inA_off, 0, D, 0);
+                st[2] = load_row<4, true>(xbase + (par ^ 1) * kPar + inB_off, 0, D, 0);
+                if (sub) {
+                  Row<4> r;
+                  if (dead || !mbox_take<4>(qa4, (unsigned)(t - 1), r))
+                    mbox_wait<4>(sub, D, dh, (unsigned)(t - 1), r, dead, status);
+                  if (!left_lds) {  // wave 0 of a strip: its first half takes A from the strip on the left
+                    if (half == 0) st[1] = r;
+                  } else {          // last wave: its second half takes B from the strip on the right
+                    if (half == 1) st[2] = r;
+                  }
+                }
+                const Row<4> cc[3] = {ch[u][1], ch[u][0], ch[u][1]};
+                sgm_step_h2x3<3, 1, 5>(st, cc, pen, p1v, below, above, drop_tail);
+                Vh[1] = st[0];
+                Ah[0] = st[1];
+                Bh[1] = st[2];
+              }
+            }
+            if (sub && !dead && t + 1 < H) mbox_peek<4>(sub, D, dh, (unsigned)t, qa4);
+            if ((y & (kT - 1)) == (UP ? 0 : kT - 1)) {
+              float *r0 = rowV + (long long)(y >> 3) * W * D;
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                store_row<4, true, true>(r0 + (loff + (unsigned)(j * D)), 0, D, 0, Vh[j]);
+                store_row<4, true, true>(r0 + kstride + (loff + (unsigned)(j * D)), 0, D, 0, Ah[j]);
+                store_row<4, true, true>(r0 + 2 * kstride + (loff + (unsigned)(j * D)), 0, D, 0, Bh[j]);
+              }
+            }
+            if (colA) {
+              if (half == 1) store_row<4, true, true>(colA + (unsigned)dh, 0, D, 0, Ah[1]);
+              colA += col_step;
+            }
+            if (colB) {
+              if (half == 0) store_row<4, true, true>(colB + (unsigned)dh, 0, D, 0, Bh[0]);
+              colB += col_step;
+            }
+            y += UP ? -1 : 1;
+            refill(ch[u], ich[u], iph[u]);
+            lds_barrier();
+          }
+        }
+      }
+      return;
+    }
+  } else if (VPL <= 2 && xa >= 1 && xa + CW <= W - 1) {
     const long row_step = (long)(UP ? -1 : 1) * W * D;  // elements from one row to the next
     const float *cnext = cost + (size_t)(UP ? H - 1 : 0) * W * D + (size_t)xa * D + d0;  // this lane's part of the next row to fetch
     int t_next = 0;
@@ -341,8 +480,8 @@ __global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float
             for (int j = 0; j < CW; ++j) { V[j] = cb[u][j]; A[j] = cb[u][j]; B[j] = cb[u][j]; }
             if (pubA) mbox_publish<VPL>(pubA, D, d0, 0u, A[CW - 1]);
             if (pubB) mbox_publish<VPL>(pubB, D, d0, 0u, B[0]);
-            store_row<VPL, true>(&xch[par][0][wv][0], 0, D, d0, A[CW - 1]);
-            store_row<VPL, true>(&xch[par][1][wv][0], 0, D, d0, B[0]);
+            store_row<VPL, true>(&xch[par][0][slot_pubA][0], 0, D, d0, A[CW - 1]);
+            store_row<VPL, true>(&xch[par][1][slot_pubB][0], 0, D, d0, B[0]);
           } else {
 #pragma unroll
             for (int i = 0; i < CW; ++i) {
@@ -357,10 +496,10 @@ __global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float
                 prev[2] = B[jb + 1];
               } else {
                 STM_SWEEP_STAMP(2);
-                if (left_lds) prev[1] = load_row<VPL, true>(&xch[par ^ 1][0][wv - 1][0], 0, D, d0);
+                if (left_lds) prev[1] = load_row<VPL, true>(&xch[par ^ 1][0][slot_subA][0], 0, D, d0);
                 else if (dead || !mbox_take<VPL>(qa, (unsigned)(t - 1), prev[1]))
                   mbox_wait<VPL>(subA, D, d0, (unsigned)(t - 1), prev[1], dead, status);
-                if (right_lds) prev[2] = load_row<VPL, true>(&xch[par ^ 1][1][wv + 1][0], 0, D, d0);
+                if (right_lds) prev[2] = load_row<VPL, true>(&xch[par ^ 1][1][slot_subB][0], 0, D, d0);
                 else if (dead || !mbox_take<VPL>(qb, (unsigned)(t - 1), prev[2]))
                   mbox_wait<VPL>(subB, D, d0, (unsigned)(t - 1), prev[2], dead, status);
                 STM_SWEEP_STAMP(3);
@@ -374,8 +513,8 @@ __global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float
               if (i == 0) {
                 if (pubA) mbox_publish<VPL>(pubA, D, d0, (unsigned)t, A[CW - 1]);
                 if (pubB) mbox_publish<VPL>(pubB, D, d0, (unsigned)t, B[0]);
-                store_row<VPL, true>(&xch[par][0][wv][0], 0, D, d0, A[CW - 1]);
-                store_row<VPL, true>(&xch[par][1][wv][0], 0, D, d0, B[0]);
+                store_row<VPL, true>(&xch[par][0][slot_pubA][0], 0, D, d0, A[CW - 1]);
+                store_row<VPL, true>(&xch[par][1][slot_pubB][0], 0, D, d0, B[0]);
                 STM_SWEEP_STAMP(1);
               }
             }
@@ -440,8 +579,8 @@ __global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float
             for (int j = 0; j < CW; ++j) { V[j] = c[j]; A[j] = c[j]; B[j] = c[j]; }
             if (pubA) mbox_publish<VPL>(pubA, D, d0, 0u, A[CW - 1]);
             if (pubB) mbox_publish<VPL>(pubB, D, d0, 0u, B[0]);
-            store_row<VPL, true>(&xch[par][0][wv][0], 0, D, d0, A[CW - 1]);
-            store_row<VPL, true>(&xch[par][1][wv][0], 0, D, d0, B[0]);
+            store_row<VPL, true>(&xch[par][0][slot_pubA][0], 0, D, d0, A[CW - 1]);
+            store_row<VPL, true>(&xch[par][1][slot_pubB][0], 0, D, d0, B[0]);
           } else {
             // CW batches of three independent steps: batch i steps A into column CW-1-i (from
             // the column on its left), B into column i (from the column on its right) and V in
@@ -463,14 +602,14 @@ __global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float
                 STM_SWEEP_STAMP(2);
                 // What arrives: A for the first column, B for the last.
                 if (has_left) {
-                  if (left_lds) prev[1] = load_row<VPL, true>(&xch[par ^ 1][0][wv - 1][0], 0, D, d0);
+                  if (left_lds) prev[1] = load_row<VPL, true>(&xch[par ^ 1][0][slot_subA][0], 0, D, d0);
                   else if (dead || !mbox_take<VPL>(qa, (unsigned)(t - 1), prev[1]))
                     mbox_wait<VPL>(subA, D, d0, (unsigned)(t - 1), prev[1], dead, status);
                 } else {
                   prev[1] = c[0];
                 }
                 if (has_right) {
-                  if (right_lds) prev[2] = load_row<VPL, true>(&xch[par ^ 1][1][wv + 1][0], 0, D, d0);
+                  if (right_lds) prev[2] = load_row<VPL, true>(&xch[par ^ 1][1][slot_subB][0], 0, D, d0);
                   else if (dead || !mbox_take<VPL>(qb, (unsigned)(t - 1), prev[2]))
                     mbox_wait<VPL>(subB, D, d0, (unsigned)(t - 1), prev[2], dead, status);
                 } else {
@@ -488,8 +627,8 @@ __global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float
               if (i == 0) {
                 if (pubA) mbox_publish<VPL>(pubA, D, d0, (unsigned)t, A[CW - 1]);
                 if (pubB) mbox_publish<VPL>(pubB, D, d0, (unsigned)t, B[0]);
-                store_row<VPL, true>(&xch[par][0][wv][0], 0, D, d0, A[CW - 1]);
-                store_row<VPL, true>(&xch[par][1][wv][0], 0, D, d0, B[0]);
+                store_row<VPL, true>(&xch[par][0][slot_pubA][0], 0, D, d0, A[CW - 1]);
+                store_row<VPL, true>(&xch[par][1][slot_pubB][0], 0, D, d0, B[0]);
                 STM_SWEEP_STAMP(1);
               }
             }

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Builds the product library and the diagnostic (stamped) variant tools/_probe/libstm_stamps.so;
-# options: usage (register / scratch use), recompute, ablate (timing probes, see below).
+# options: usage (register / scratch use), recompute, ablate (timing probes, see below),
+# microbench (tools/valu_microbench.hip, tools/h2_dpp_check.hip).
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 C=$ROOT/stereo-matching_amd/csrc
@@ -21,6 +22,10 @@ if [ "$1" = "ablate" ]; then
     /opt/rocm/bin/hipcc $FL -DSTM_TILE_ABLATE=$A -c $C/stm_sgm_tiled.hip -o /tmp/isa/tiled_ablate$A.o 2>&1 | grep -E "error|warning:" || true
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/tools/_probe/libstm_ablate$A.so $C/stm_api.o $C/stm_wta.o $C/stm_ssd.o $C/stm_birchfield.o $C/stm_sgm.o /tmp/isa/tiled_ablate$A.o $C/stm_dp.o $C/stm_sgm_exact.o
   done
+fi
+if [ "$1" = "microbench" ]; then
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -Wno-unused-result -o $ROOT/tools/_probe/valu_microbench $ROOT/tools/valu_microbench.hip
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -Wno-unused-result -o $ROOT/tools/_probe/h2_dpp_check $ROOT/tools/h2_dpp_check.hip
 fi
 if [ "$1" = "usage" ]; then
   /opt/rocm/bin/hipcc $FL --cuda-device-only -S $C/stm_sgm_tiled.hip -o /tmp/isa/tiled.s -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "Function Name|VGPRs:|Spill|Scratch" | sed 's/.*remark: *//; s/ \[-Rpass.*//' | paste - - - - - | sed 's/_ZN3stm12_GLOBAL__N_1//; s/EvPKfS3.*E\t/\t/' | grep -E "ILi[24]E"

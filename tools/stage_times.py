@@ -29,7 +29,8 @@ def timeit(fn, reps=5):
 
 
 for name, H, W, D, B in (("teddy", 375, 450, 128, 16), ("teddy", 375, 450, 128, 1),
-                         ("1080p", 1080, 1920, 256, 2), ("1080p", 1080, 1920, 256, 1)):
+                         ("1080p", 1080, 1920, 256, 8), ("1080p", 1080, 1920, 256, 2),
+                         ("1080p", 1080, 1920, 256, 1)):
     pairs = [synthetic_pair(H, W, s) for s in range(B)]
     L = torch.from_numpy(np.stack([p[0] for p in pairs])).to(dev)
     R = torch.from_numpy(np.stack([p[1] for p in pairs])).to(dev)
