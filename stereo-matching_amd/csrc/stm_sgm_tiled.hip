@@ -25,10 +25,16 @@
 //          bounded (a timeout sets the status word in the workspace header and the sweep
 //          finishes without waiting again).
 //        * sgm_hwalk_kernel, left-to-right and right-to-left: one wave per image row.
-//   2. TILES.  sgm_tile_kernel: one workgroup per tile loads the tile's cost rows into LDS
-//      once, rebuilds all eight directions inside the tile from the border states (every
-//      path crosses at most 8 pixels of a tile), adds them in the reference order into an
-//      LDS-resident sum tile and writes the finished rows (and/or their winner-takes-all).
+//   2. TILES.  sgm_tile_kernel (D = 256, 64) / sgm_tile_h2_kernel (D = 128): one workgroup
+//      per tile loads the tile's cost rows into LDS once, rebuilds all eight directions
+//      inside the tile from the border states (every path crosses at most 8 pixels of a
+//      tile), adds them in the reference order into an LDS-resident sum tile and writes the
+//      finished rows (and/or their winner-takes-all).
+//
+// At D = 128 the interior waves of the sweeps and the tile kernel hold TWO pixels per wave
+// (32 lanes x 4 disparities each, stm_sgm_step.h: sgm_step_h2*): the kernels are bound by
+// vector instructions issued there, and a wave-wide minimum per 128 disparities is most of a
+// step's cost.
 //
 // Traffic per (pixel, d): 5 x 4 (cost reads) + 2 x 6 (border states written and read)
 // + 4 (sum written; 0 with the fused reduction) = 32-36 bytes.
