@@ -688,6 +688,7 @@ struct HwalkArgs {
   TiledGeom G;
   float p1, p2;
   int dlim;
+  int only_left;  // D = 128: the tile kernel carries the left-to-right states along its tile rows
 };
 
 template <int VPL>
@@ -704,9 +705,9 @@ __global__ __launch_bounds__(256) void sgm_hwalk_kernel(const float *__restrict_
   const int lane = threadIdx.x & 63;
   int wave = wave_uniform((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
   const int H = G.H, W = G.W;
-  if (wave >= 2 * H * G.batch) return;
-  const bool left = wave & 1;  // 0: left-to-right, 1: right-to-left
-  wave >>= 1;
+  if (wave >= (P.only_left ? 1 : 2) * H * G.batch) return;
+  const bool left = P.only_left ? true : (wave & 1);  // 0: left-to-right, 1: right-to-left
+  if (!P.only_left) wave >>= 1;
   const int b = wave / H, y = wave - b * H;
   const int d0 = lane * VPL;
   const float *cost = cost_all + ((size_t)b * H + y) * (size_t)W * D;
@@ -1542,11 +1543,27 @@ __device__ __forceinline__ void h2_pair_init(H2Pair &K, const TiledGeom &G, int 
   }
 }
 
+// Position of a tile for a workgroup that owns whole tile rows (rows blockIdx.x, + gridDim.x,
+// ... of batch * nTR) and walks each from left to right.
+struct TileRowWalk {
+  int b, trow, tcol, row;
+  __device__ __forceinline__ void init(int r, const TiledGeom &G) {
+    row = r;
+    b = r / G.nTR;
+    trow = r - b * G.nTR;
+    tcol = 0;
+  }
+  __device__ __forceinline__ void next(const TiledGeom &G, int stride) {
+    if (++tcol == G.nTC) init(row + stride, G);
+  }
+};
+
 // A tile's terms of the entry addresses.
 struct H2TileBase {
   const float *row, *col;
 };
-__device__ __forceinline__ H2TileBase h2_tile_base(float *ws, const TiledGeom &G, const TileWalk &t) {
+template <typename Walk>
+__device__ __forceinline__ H2TileBase h2_tile_base(float *ws, const TiledGeom &G, const Walk &t) {
   H2TileBase T;
   T.row = ws + G.rowb_off + (long long)t.b * G.rowb_img + (long long)(t.trow * G.W + t.tcol * kT) * G.D;
   T.col = ws + G.colb_off + (long long)t.b * G.colb_img + (long long)(t.tcol * G.H + t.trow * kT) * G.D;
@@ -1631,7 +1648,7 @@ __device__ __forceinline__ void h2_pair(const H2Pair &K, const Row<4> (&E)[4], i
                                         int true_paths, const float *Ct,
                                         float *St, const float *Ip, float p1, float p2, StepCtxH2 &X, int lane,
                                         int hl16, int W, int x0, int y0, float *__restrict__ out,
-                                        int32_t *__restrict__ disp, Between between) {
+                                        int32_t *__restrict__ disp, Row<4> &exit_f, Between between) {
   constexpr int dx = PhaseDir<PHASE>::dx, dy = PhaseDir<PHASE>::dy;
   constexpr int pstep = dy * kT + dx;
   constexpr int kPixBytes = 128 * 4;
@@ -1702,6 +1719,7 @@ __device__ __forceinline__ void h2_pair(const H2Pair &K, const Row<4> (&E)[4], i
     fstep(integral_constant<int, 4>()); fstep(integral_constant<int, 5>());
     fstep(integral_constant<int, 6>()); fstep(integral_constant<int, 7>());
   }
+  if (PHASE == 0) exit_f = LF[kT - 1];  // the rightward state where the lane's row leaves the tile
   between();
   // The update, four slots at a time: their sums are requested together (the compiler cannot
   // move an LDS read above the previous slot's write -- it does not know that slots never
@@ -1774,10 +1792,11 @@ template <int PHASE, int FINAL, typename Between>
 __device__ __forceinline__ void h2_pair_w(int w, int half, const H2Pair &K, const Row<4> (&E)[4], int cls,
                                           const TileArgs &P, const float *Ct, float *St, const float *Ip,
                                           StepCtxH2 &X, int lane, int hl16, int x0, int y0,
-                                          float *__restrict__ out, int32_t *__restrict__ disp, Between between) {
+                                          float *__restrict__ out, int32_t *__restrict__ disp, Row<4> &exit_f,
+                                          Between between) {
 #define STM_H2_PAIR(NA)                                                                              \
   h2_pair<PHASE, NA, FINAL>(K, E, cls, w, half, P.G, P.true_paths, Ct, St, Ip, P.p1, P.p2, X, lane, hl16, \
-                            P.G.W, x0, y0, out, disp, between)
+                            P.G.W, x0, y0, out, disp, exit_f, between)
   if constexpr (PHASE < 2) {
     STM_H2_PAIR(kT);
   } else {
@@ -1797,7 +1816,7 @@ template <int PHASE, int FINAL, typename Between>
 __device__ __forceinline__ void h2_pair_generic(int w, int tw, int th, const float *Ct, float *St, const float *Ip,
                                                 const TileArgs &P, const BorderBase &B, int x0, int y0,
                                                 float *__restrict__ out, int32_t *__restrict__ disp, StepCtx &X,
-                                                int lane, Between between) {
+                                                int lane, float *exits, Between between) {
   const int d0 = lane * 2;
   PhaseGeom g[2];
   Slots<PHASE> sl[2];
@@ -1809,6 +1828,8 @@ __device__ __forceinline__ void h2_pair_generic(int w, int tw, int th, const flo
     load_entries<2, PHASE>(E, g[i], B, P.G, x0, y0, d0);
     sl[i].init(g[i]);
     tile_chains<2, PHASE>(sl[i], E, Ct, Ip, P.p1, P.p2, X, lane, LF[i], LI[i]);
+    if (PHASE == 0 && exits && tw == kT && 2 * w + i < th)  // the rightward state where row 2 w + i leaves the tile
+      store_row<2, true>(exits + (size_t)(2 * w + i) * 128, 0, 128, d0, LF[i][kT - 1]);
   }
   between();
 #pragma unroll
@@ -1831,7 +1852,6 @@ __global__ __launch_bounds__(4 * 64, 2) void sgm_tile_h2_kernel(const float *__r
   const int half = lane >> 5, hl = lane & 31;
   const int d0 = hl * 4, hl16 = hl * 16;
   const size_t npix = (size_t)G.H * G.W;
-  const int ntiles = G.batch * G.nTR * G.nTC;  // < 2^31 (shape_ok)
   const int stride = (int)gridDim.x;
   StepCtxH2 X;
   X.init(P.p1, hl, P.dlim);
@@ -1842,22 +1862,31 @@ __global__ __launch_bounds__(4 * 64, 2) void sgm_tile_h2_kernel(const float *__r
   h2_pair_init<1>(K1, G, w, half);
   h2_pair_init<2>(K2, G, w, half);
   h2_pair_init<3>(K3, G, w, half);
-  TileWalk cur_t, next_t;  // the tile being computed / the one being prefetched
-  cur_t.init((int)blockIdx.x, stride, G);
+  // A workgroup owns whole tile rows and walks them left to right: the rightward state with
+  // which a row leaves a tile is the next tile's entry state and stays in registers (between
+  // two tiles of this form; otherwise it goes through the column border states, which every
+  // tile writes) -- there is no left-to-right horizontal walk at D = 128, i.e. one read of the
+  // cost volume fewer.
+  const int nrows = G.batch * G.nTR;
+  TileRowWalk cur_t, next_t;  // the tile being computed / the one being prefetched
+  cur_t.init((int)blockIdx.x, G);
+  if (cur_t.row >= nrows) return;
   next_t = cur_t;
 
   // A tile is interior when all of its neighbours exist (every line enters from a border state).
-  auto interior = [&](const TileWalk &t) {
+  auto interior = [&](const TileRowWalk &t) {
     return t.trow >= 1 && t.trow <= G.nTR - 2 && t.tcol >= 1 && t.tcol <= G.nTC - 2 &&
            (t.trow + 1) * kT <= G.H && (t.tcol + 1) * kT <= G.W;
   };
   Row<4> cpre[kT];  // next tile: tile row 2 w + half of the cost tile
   float ipre = 0.0f;
   Row<4> E0[4], E1[4];  // next tile: entry states of pairs 0 and 1 (interior tiles)
+  Row<4> carry;         // the previous tile's rightward exit state of row 2 w + half
+  bool have_carry = false;
   // Every prefetch redefines all of its registers unconditionally (past the last tile it
   // re-reads that tile; rows and samples outside a partial tile are clamped into it; the
   // entry states of a tile that is not interior are read at the workspace's first border row).
-  auto prefetch_cost = [&](const TileWalk &t) {
+  auto prefetch_cost = [&](const TileRowWalk &t) {
     const int x0 = t.tcol * kT, y0 = t.trow * kT;
     const int tw = imin(kT, G.W - x0), th = imin(kT, G.H - y0);
     const float *cost = cost_all + (size_t)t.b * npix * D;
@@ -1870,7 +1899,7 @@ __global__ __launch_bounds__(4 * 64, 2) void sgm_tile_h2_kernel(const float *__r
     const int gy = imin(y0 + r > 0 ? y0 + r : 0, G.H - 1), gx = imin(x0 + c > 0 ? x0 + c : 0, G.W - 1);
     ipre = image_all[(size_t)t.b * npix + (unsigned)(gy * G.W + gx)];
   };
-  auto entry_base = [&](const TileWalk &t) {
+  auto entry_base = [&](const TileRowWalk &t) {
     H2TileBase T = h2_tile_base(ws, G, t);
     if (!interior(t)) {  // valid dummy addresses: this image's first border row, far enough in
       T.row = ws + G.rowb_off + (long long)t.b * G.rowb_img + (long long)(G.W + kT) * D;
@@ -1881,13 +1910,14 @@ __global__ __launch_bounds__(4 * 64, 2) void sgm_tile_h2_kernel(const float *__r
   prefetch_cost(next_t);
   h2_load_entries<2>(E0, K0, entry_base(next_t), d0);
   h2_load_entries<2>(E1, K1, entry_base(next_t), d0);
-  for (int id = (int)blockIdx.x; id < ntiles; id += stride) {
+  for (;;) {
     const int b = cur_t.b, x0 = cur_t.tcol * kT, y0 = cur_t.trow * kT;
     const int tw = imin(kT, G.W - x0), th = imin(kT, G.H - y0);
     float *out = out_all ? out_all + (size_t)b * npix * D : nullptr;
     int32_t *disp = disp_all ? disp_all + (size_t)b * npix : nullptr;
 #ifdef STM_TILE_STAMPS
-    const int tile = id < 4096 ? id : 4096;
+    const int tid_ = cur_t.row * G.nTC + cur_t.tcol;
+    const int tile = tid_ < 4096 ? tid_ : 4096;
     const int w16 = w;
 #endif
     STM_STAMP(0);
@@ -1899,44 +1929,65 @@ __global__ __launch_bounds__(4 * 64, 2) void sgm_tile_h2_kernel(const float *__r
     }
     if (threadIdx.x < (kT + 2) * (kT + 2)) Ip[threadIdx.x] = ipre;
     Row<4> Ea[4], Eb[4];
-    Ea[0] = E0[0]; Ea[1] = E0[1];
+    Ea[0] = have_carry ? carry : E0[0];
+    Ea[1] = E0[1];
     Eb[0] = E1[0]; Eb[1] = E1[1];
     STM_STAMP(1);
     lds_barrier();
     STM_STAMP(2);
-    if (id + stride < ntiles) next_t.next(G);
+    bool more;
+    {
+      TileRowWalk n = cur_t;
+      n.next(G, stride);
+      more = n.row < nrows;
+      if (more) next_t = n;
+    }
+    // Where the rows of this tile leave it to the right (column border states of direction 0).
+    float *exits = colb_ptr(ws, G, b, 0, cur_t.tcol, y0);
     // A global load takes several times as long as a pair (2-4 us against ~1 us), and results
     // return in issue order: the entry states of pairs 2 and 3 are requested now, then the next
     // tile's cost rows; the next tile's pairs 0 and 1 follow once pairs 0 and 1 are done.
     if (fast) {
       const H2TileBase T = h2_tile_base(ws, G, cur_t);
-      Row<4> Ec[4], Ed[4];
+      Row<4> Ec[4], Ed[4], unused;
       h2_load_entries<4>(Ec, K2, T, d0);
       h2_load_entries<4>(Ed, K3, T, d0);
       prefetch_cost(next_t);
-      h2_pair_w<0, FINAL>(w, half, K0, Ea, 1, P, Ct, St, Ip, X, lane, hl16, x0, y0, out, disp, [] {});
-      h2_pair_w<1, FINAL>(w, half, K1, Eb, 1, P, Ct, St, Ip, X, lane, hl16, x0, y0, out, disp, [] { lds_barrier(); });
+      h2_pair_w<0, FINAL>(w, half, K0, Ea, 1, P, Ct, St, Ip, X, lane, hl16, x0, y0, out, disp, carry, [] {});
+      have_carry = true;
+      store_row<4, true>(exits + (size_t)(2 * w + half) * D, 0, D, d0, carry);
+      h2_pair_w<1, FINAL>(w, half, K1, Eb, 1, P, Ct, St, Ip, X, lane, hl16, x0, y0, out, disp, unused,
+                          [] { lds_barrier(); });
       h2_load_entries<2>(E0, K0, entry_base(next_t), d0);
       h2_load_entries<2>(E1, K1, entry_base(next_t), d0);
-      h2_pair_w<2, FINAL>(w, half, K2, Ec, cls2, P, Ct, St, Ip, X, lane, hl16, x0, y0, out, disp,
+      h2_pair_w<2, FINAL>(w, half, K2, Ec, cls2, P, Ct, St, Ip, X, lane, hl16, x0, y0, out, disp, unused,
                           [] { lds_barrier(); });
       STM_STAMP(3);
-      h2_pair_w<3, FINAL>(w, half, K3, Ed, cls3, P, Ct, St, Ip, X, lane, hl16, x0, y0, out, disp,
+      h2_pair_w<3, FINAL>(w, half, K3, Ed, cls3, P, Ct, St, Ip, X, lane, hl16, x0, y0, out, disp, unused,
                           [&] { STM_STAMP(4); lds_barrier(); STM_STAMP(5); });
       STM_STAMP(6);
     } else {
       prefetch_cost(next_t);
+      // (the previous tile of this row, if it took the other form, stored this tile's
+      // rightward entry states a moment ago: same wave, same addresses)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const BorderBase B = border_base(ws, G, b);
-      h2_pair_generic<0, FINAL>(w, tw, th, Ct, St, Ip, P, B, x0, y0, out, disp, X1, lane, [] {});
-      h2_pair_generic<1, FINAL>(w, tw, th, Ct, St, Ip, P, B, x0, y0, out, disp, X1, lane, [] { lds_barrier(); });
+      have_carry = false;
+      h2_pair_generic<0, FINAL>(w, tw, th, Ct, St, Ip, P, B, x0, y0, out, disp, X1, lane, exits, [] {});
+      h2_pair_generic<1, FINAL>(w, tw, th, Ct, St, Ip, P, B, x0, y0, out, disp, X1, lane, nullptr,
+                                [] { lds_barrier(); });
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... and this tile's for the next one
       h2_load_entries<2>(E0, K0, entry_base(next_t), d0);
       h2_load_entries<2>(E1, K1, entry_base(next_t), d0);
-      h2_pair_generic<2, FINAL>(w, tw, th, Ct, St, Ip, P, B, x0, y0, out, disp, X1, lane, [] { lds_barrier(); });
-      h2_pair_generic<3, FINAL>(w, tw, th, Ct, St, Ip, P, B, x0, y0, out, disp, X1, lane, [] { lds_barrier(); });
+      h2_pair_generic<2, FINAL>(w, tw, th, Ct, St, Ip, P, B, x0, y0, out, disp, X1, lane, nullptr,
+                                [] { lds_barrier(); });
+      h2_pair_generic<3, FINAL>(w, tw, th, Ct, St, Ip, P, B, x0, y0, out, disp, X1, lane, nullptr,
+                                [] { lds_barrier(); });
     }
-    cur_t = next_t;
     lds_barrier();
     STM_STAMP(7);
+    if (!more) break;
+    cur_t = next_t;
   }
 }
 
@@ -2008,7 +2059,8 @@ int run_tiled(const float *cost, const float *left, float *out, int32_t *disp, c
   {
     HwalkArgs A;
     A.G = G; A.p1 = p1; A.p2 = p2; A.dlim = dlim;
-    const long waves = 2l * G.H * batch;
+    A.only_left = VPL == 2;
+    const long waves = (A.only_left ? 1l : 2l) * G.H * batch;
     hipLaunchKernelGGL((sgm_hwalk_kernel<VPL>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s,
                        cost, left, ws, A);
     int rc = check_launch("stm_sgm_f32 (tiled: horizontal walks)");
@@ -2040,8 +2092,8 @@ int run_tiled(const float *cost, const float *left, float *out, int32_t *disp, c
     const long long ntiles = (long long)G.nTR * G.nTC * batch;
     if constexpr (VPL == 2) {
       // D = 128: four-wave workgroups, two lines of a pair per wave, two workgroups per CU
-      const long long wgs = (long long)device_cus() * 2;
-      const dim3 grid((unsigned)(ntiles < wgs ? ntiles : wgs)), block(4 * 64);
+      const long long wgs = (long long)device_cus() * 2, rows = (long long)G.nTR * batch;
+      const dim3 grid((unsigned)(rows < wgs ? rows : wgs)), block(4 * 64);
       if (final_mode == 0)
         hipLaunchKernelGGL((sgm_tile_h2_kernel<0>), grid, block, 0, s, cost, left, out, disp, ws, A);
       else if (final_mode == 1)
