@@ -191,16 +191,24 @@ __device__ __forceinline__ float rot1(float x) {
                                                             0xf, false));
 }
 
-template <int O>
+// G: blocks whose cost pieces are fetched together, G * O * 4 = 128 bytes (one line) for
+// O <= 16 when D is a multiple of 32 (G = 1: a piece per block, as above).  Pieces of 64 bytes
+// and less, a kilobyte apart, are what the batch throughput hit at ~3 TB/s.
+template <int O, int G>
 __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ vol_all,
                                                      int8_t *__restrict__ path_all,
                                                      float *__restrict__ rowfin_all,
                                                      const DpShape S) {
   constexpr int P = 16 * O;
-  constexpr int LP = O / 4;          // lanes per cost piece (16 bytes each)
-  constexpr int PPI = 64 / LP;       // pieces per cooperative load instruction
-  constexpr int LD = O + 1;          // padded LDS row: conflict-free ds_read_b32 by 64 lanes
-  __shared__ float tile[2][64 * LD];
+  constexpr int LP = O / 4;          // load instructions per fetch; dwords of path bytes per block
+  constexpr int LPG = G * O / 4;     // lanes per cost piece (16 bytes each)
+  constexpr int PPI = 64 / LPG;      // pieces per cooperative load instruction
+  constexpr int NGC = 16 / G;        // pieces per column
+  constexpr int LD = G * O + 1;      // padded LDS row: conflict-free ds_read_b32 by 64 lanes
+  // G = 1: two buffers (this block's pieces / the next block's).  G > 1: a lane's piece lasts G
+  // blocks and its successor is parked at the end of the block that consumes its last part,
+  // so one buffer does.
+  __shared__ float tile[G == 1 ? 2 : 1][64 * LD];
   // Path bytes of the column each lane is working on, collected until a 64-byte run of the
   // column's record is complete (FL blocks of O bytes; the whole column for O >= 32), which
   // then leaves in one piece (see the end of the loop).  Keeping whole columns here (16 KB at
@@ -234,46 +242,46 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
     init[rq][d] = x;
   }
 
-  // Cooperative fetch of the cost pieces a block will consume: instruction u, lane i serves
-  // piece pi = u*PPI + i/LP (the piece lane pi owns), 16-byte part i%LP.  The position of
-  // every served piece advances by one chunk per block (O disparities down its column, then
-  // on to the column 16 to the right), so it is kept incrementally; pieces without work
-  // read as +inf, which turns into +inf outputs without a select in the dependent chain.
-  int fq[LP], fcol[LP], fd0[LP];
-  size_t fat[LP];
-  bool frow[LP];
-#pragma unroll
-  for (int u = 0; u < LP; ++u) {
-    const int pi = u * PPI + lane / LP, part = lane % LP;
-    const int prow = blockIdx.x * 4 + (pi >> 4), pv = pi & 15;
-    frow[u] = prow < H;
-    fq[u] = -pv;            // blocks until the owner's first column starts
-    fcol[u] = pv;
-    fd0[u] = 0;
-    fat[u] = ((size_t)(frow[u] ? prow : 0) * W + pv) * D + 4 * part;
-  }
-  auto fetch = [&](float4 (&regs)[LP]) {  // fetches the next block's pieces, then advances
+  // Cooperative fetch of the cost pieces the next block will begin to consume.  At time T
+  // (block T is the next one) the lanes v = T (mod G) of every image row start a new piece:
+  // the G * O disparities from chunk T - v of their column walk (O disparities down the
+  // column per block, 16 blocks per column, then the column 16 to the right).  Instruction u,
+  // lane i serves the (u * PPI + i / LPG)-th of those 64 / G pieces, 16-byte part i % LPG.
+  // Pieces without work read as +inf, which turns into +inf outputs without a select in the
+  // dependent chain.
+  int T = 0;
+  auto fetch = [&](float4 (&regs)[LP]) {
+    const int set = T & (G - 1), n = T / G;
 #pragma unroll
     for (int u = 0; u < LP; ++u) {
-      const bool ok = fq[u] >= 0 && fcol[u] < W && fd0[u] < D && frow[u];
-      const float4 x = *reinterpret_cast<const float4 *>(vol + (ok ? fat[u] : 0));
+      const int j = u * PPI + lane / LPG, part = lane % LPG;
+      const int prow = blockIdx.x * 4 + j / NGC, jj = j % NGC;
+      const int pv = G * jj + set;
+      const int k = n - jj;                       // the piece's index in its lane's walk
+      const int col = pv + 16 * (k / NGC);        // (k >= 0 where it matters)
+      const int pd0 = G * O * (k % NGC);
+      const bool ok = k >= 0 && col < W && pd0 < D && prow < H;
+      const size_t at = ((size_t)(ok ? prow : 0) * W + (ok ? col : 0)) * D + (ok ? pd0 : 0) + 4 * part;
+      const float4 x = *reinterpret_cast<const float4 *>(vol + at);
       regs[u] = ok ? x : make_float4(inf, inf, inf, inf);
-      if (fq[u] >= 0) {
-        fd0[u] += O;
-        fat[u] += O;
-        if (fd0[u] == P) { fd0[u] = 0; fcol[u] += 16; fat[u] += (size_t)16 * D - P; }
-      }
-      ++fq[u];
     }
+    ++T;
   };
+  // Parks what the fetch at time T - 1 brought.
   auto park = [&](int buf, const float4 (&regs)[LP]) {
+    const int set = (T - 1) & (G - 1);
 #pragma unroll
     for (int u = 0; u < LP; ++u) {
-      const int pi = u * PPI + lane / LP, part = lane % LP;
+      const int j = u * PPI + lane / LPG, part = lane % LPG;
+      const int pi = (j / NGC) * 16 + G * (j % NGC) + set;  // the lane that owns the piece
       float *dst = &tile[buf][pi * LD + 4 * part];
       dst[0] = regs[u].x; dst[1] = regs[u].y; dst[2] = regs[u].z; dst[3] = regs[u].w;
     }
   };
+  if (G > 1) {  // lanes whose first piece has not arrived yet read +inf
+    for (int e = lane; e < 64 * LD; e += 64) tile[0][e] = inf;
+    wave_lds_handoff();
+  }
 
   float4 regs[LP];
   fetch(regs);
@@ -296,7 +304,7 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
     // their outputs +inf without a select in the chain.
     float cst[O], outs[O];
 #pragma unroll
-    for (int j = 0; j < O; ++j) cst[j] = tile[cur][lane * LD + j];
+    for (int j = 0; j < O; ++j) cst[j] = tile[G == 1 ? cur : 0][lane * LD + (q & (G - 1)) * O + j];
     unsigned pk[LP];
 #pragma unroll
     for (int u = 0; u < LP; ++u) pk[u] = 0;
@@ -381,8 +389,8 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
         }
       }
     }
-    park(cur ^ 1, regs);
-    wave_lds_handoff();  // tile[cur ^ 1] (and pbuf) change hands between iterations
+    park(G == 1 ? cur ^ 1 : 0, regs);
+    wave_lds_handoff();  // the parked pieces (and pbuf) change hands between iterations
   }
   // Flush the final costs (fin[] was written by the lanes that own the last column).
   float *rowfin = rowfin_all + ((size_t)b * H + (rowok ? row : 0)) * D;
@@ -501,10 +509,13 @@ extern "C" int stm_dp_f32(const float *volume, int8_t *path, float *row_final, i
                          ((reinterpret_cast<uintptr_t>(path) & 15) == 0);
   if (wavefront) {
     const dim3 wgrid((H + 3) / 4, batch), wblock(64);
-    if (O == 8) hipLaunchKernelGGL(dp_tile_kernel<8>, wgrid, wblock, 0, s, volume, path, row_final, S);
-    else if (O == 16) hipLaunchKernelGGL(dp_tile_kernel<16>, wgrid, wblock, 0, s, volume, path, row_final, S);
-    else if (O == 32) hipLaunchKernelGGL(dp_tile_kernel<32>, wgrid, wblock, 0, s, volume, path, row_final, S);
-    else hipLaunchKernelGGL(dp_tile_kernel<64>, wgrid, wblock, 0, s, volume, path, row_final, S);
+    const bool lines = D % 32 == 0;  // whole 128-byte pieces
+    if (O == 8 && lines) hipLaunchKernelGGL((dp_tile_kernel<8, 4>), wgrid, wblock, 0, s, volume, path, row_final, S);
+    else if (O == 8) hipLaunchKernelGGL((dp_tile_kernel<8, 1>), wgrid, wblock, 0, s, volume, path, row_final, S);
+    else if (O == 16 && lines) hipLaunchKernelGGL((dp_tile_kernel<16, 2>), wgrid, wblock, 0, s, volume, path, row_final, S);
+    else if (O == 16) hipLaunchKernelGGL((dp_tile_kernel<16, 1>), wgrid, wblock, 0, s, volume, path, row_final, S);
+    else if (O == 32) hipLaunchKernelGGL((dp_tile_kernel<32, 1>), wgrid, wblock, 0, s, volume, path, row_final, S);
+    else hipLaunchKernelGGL((dp_tile_kernel<64, 1>), wgrid, wblock, 0, s, volume, path, row_final, S);
   } else {
 #define STM_DP_LAUNCH(V)                                                                              \
   do {                                                                                                \
