@@ -61,10 +61,12 @@ def test_tiled_sgm_corrected_modes(device, oracle, H, W, D, paths, full_min):
     assert_same_bits(got.cpu().numpy(), want, "tiled sgm %s full_min=%s" % (paths, full_min))
 
 
-@pytest.mark.parametrize("H,W,D,B", [(14, 31, 64, 3), (31, 14, 64, 3), (40, 300, 64, 70), (20, 500, 256, 20)])
+@pytest.mark.parametrize("H,W,D,B", [(14, 31, 64, 3), (31, 14, 64, 3), (40, 300, 64, 70), (20, 500, 256, 20),
+                                     (40, 90, 128, 5), (100, 60, 128, 50), (60, 100, 128, 9)])
 def test_tiled_sgm_batches(device, oracle, H, W, D, B):
-    """Batches: per-image mailboxes and border states; the last two need several sweep
-    launches (more column strips than the chip has CUs)."""
+    """Batches: per-image mailboxes and border states; (40, 300) and (20, 500) need several sweep
+    launches (more column strips than the chip has CUs); the D = 128 cases run the tile kernel
+    whose workgroups own whole tile rows (more rows than workgroups in (100, 60, 128, 50))."""
     import stereomatch
     rng = np.random.default_rng(B + H)
     C = np.stack([_random_volume(rng, H, W, D, "float") for _ in range(B)])
