@@ -315,7 +315,7 @@ __global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float
       // xa + 2, xa + 3, four disparities per lane; a row is two batches of three steps.
       const int half = lane >> 5, hl = lane & 31, dh = hl * 4;
       const int vw = 2 * wv + half;
-      constexpr int PFH = 1;  // cost rows in flight beyond the current one (registers)
+      constexpr int PFH = 2;  // cost rows in flight beyond the current one
       // Addresses are a wave-uniform base plus this lane's 32-bit offset (its half's first
       // column and its disparities).
       const unsigned loff = (unsigned)(half * 2 * D + dh);
@@ -1811,29 +1811,44 @@ __device__ __forceinline__ void h2_pair_w(int w, int half, const H2Pair &K, cons
 }
 
 // A pair of a tile that does not qualify, for one wave: its two lines after each other in the
-// one-line-per-wave forms (two values per lane).
-template <int PHASE, int FINAL, typename Between>
-__device__ __forceinline__ void h2_pair_generic(int w, int tw, int th, const float *Ct, float *St, const float *Ip,
-                                                const TileArgs &P, const BorderBase &B, int x0, int y0,
-                                                float *__restrict__ out, int32_t *__restrict__ disp, StepCtx &X,
-                                                int lane, float *exits, Between between) {
-  const int d0 = lane * 2;
+// one-line-per-wave forms (two values per lane).  The entry states of all four pairs are
+// requested at the start of the tile (h2_generic_entries): a global load takes longer than a
+// pair, and eight of them in a row were most of such a tile.
+template <int PHASE>
+struct H2GenericEntries {
   PhaseGeom g[2];
+  Entries<2, PHASE> E[2];
+};
+template <int PHASE>
+__device__ __forceinline__ void h2_generic_entries(H2GenericEntries<PHASE> &Q, int w, int tw, int th,
+                                                   const TileArgs &P, const BorderBase &B, int x0, int y0, int lane) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    Q.g[i] = tile_geom<PHASE>(2 * w + i, tw, th);
+    load_entries<2, PHASE>(Q.E[i], Q.g[i], B, P.G, x0, y0, lane * 2);
+  }
+}
+
+template <int PHASE, int FINAL, typename Between>
+__device__ __forceinline__ void h2_pair_generic(const H2GenericEntries<PHASE> &Q, int w, int tw, int th,
+                                                const float *Ct, float *St, const float *Ip, const TileArgs &P,
+                                                int x0, int y0, float *__restrict__ out,
+                                                int32_t *__restrict__ disp, StepCtx &X, int lane, float *exits,
+                                                Between between) {
+  const int d0 = lane * 2;
   Slots<PHASE> sl[2];
   Row<2> LF[2][kT], LI[2][kT];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    g[i] = tile_geom<PHASE>(2 * w + i, tw, th);
-    Entries<2, PHASE> E;
-    load_entries<2, PHASE>(E, g[i], B, P.G, x0, y0, d0);
-    sl[i].init(g[i]);
-    tile_chains<2, PHASE>(sl[i], E, Ct, Ip, P.p1, P.p2, X, lane, LF[i], LI[i]);
+    sl[i].init(Q.g[i]);
+    tile_chains<2, PHASE>(sl[i], Q.E[i], Ct, Ip, P.p1, P.p2, X, lane, LF[i], LI[i]);
     if (PHASE == 0 && exits && tw == kT && 2 * w + i < th)  // the rightward state where row 2 w + i leaves the tile
       store_row<2, true>(exits + (size_t)(2 * w + i) * 128, 0, 128, d0, LF[i][kT - 1]);
   }
   between();
 #pragma unroll
-  for (int i = 0; i < 2; ++i) tile_add<2, PHASE, FINAL>(g[i], sl[i], LF[i], LI[i], St, P, x0, y0, out, disp, lane);
+  for (int i = 0; i < 2; ++i)
+    tile_add<2, PHASE, FINAL>(Q.g[i], sl[i], LF[i], LI[i], St, P, x0, y0, out, disp, lane);
 }
 
 template <int FINAL>
@@ -1967,21 +1982,29 @@ __global__ __launch_bounds__(4 * 64, 2) void sgm_tile_h2_kernel(const float *__r
                           [&] { STM_STAMP(4); lds_barrier(); STM_STAMP(5); });
       STM_STAMP(6);
     } else {
-      prefetch_cost(next_t);
       // (the previous tile of this row, if it took the other form, stored this tile's
-      // rightward entry states a moment ago: same wave, same addresses)
+      // rightward entry states a while ago: same wave, same addresses)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const BorderBase B = border_base(ws, G, b);
       have_carry = false;
-      h2_pair_generic<0, FINAL>(w, tw, th, Ct, St, Ip, P, B, x0, y0, out, disp, X1, lane, exits, [] {});
-      h2_pair_generic<1, FINAL>(w, tw, th, Ct, St, Ip, P, B, x0, y0, out, disp, X1, lane, nullptr,
+      H2GenericEntries<0> Q0;
+      H2GenericEntries<1> Q1;
+      H2GenericEntries<2> Q2;
+      H2GenericEntries<3> Q3;
+      h2_generic_entries<0>(Q0, w, tw, th, P, B, x0, y0, lane);
+      h2_generic_entries<1>(Q1, w, tw, th, P, B, x0, y0, lane);
+      h2_generic_entries<2>(Q2, w, tw, th, P, B, x0, y0, lane);
+      h2_generic_entries<3>(Q3, w, tw, th, P, B, x0, y0, lane);
+      prefetch_cost(next_t);
+      h2_pair_generic<0, FINAL>(Q0, w, tw, th, Ct, St, Ip, P, x0, y0, out, disp, X1, lane, exits, [] {});
+      h2_pair_generic<1, FINAL>(Q1, w, tw, th, Ct, St, Ip, P, x0, y0, out, disp, X1, lane, nullptr,
                                 [] { lds_barrier(); });
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... and this tile's for the next one
       h2_load_entries<2>(E0, K0, entry_base(next_t), d0);
       h2_load_entries<2>(E1, K1, entry_base(next_t), d0);
-      h2_pair_generic<2, FINAL>(w, tw, th, Ct, St, Ip, P, B, x0, y0, out, disp, X1, lane, nullptr,
+      h2_pair_generic<2, FINAL>(Q2, w, tw, th, Ct, St, Ip, P, x0, y0, out, disp, X1, lane, nullptr,
                                 [] { lds_barrier(); });
-      h2_pair_generic<3, FINAL>(w, tw, th, Ct, St, Ip, P, B, x0, y0, out, disp, X1, lane, nullptr,
+      h2_pair_generic<3, FINAL>(Q3, w, tw, th, Ct, St, Ip, P, x0, y0, out, disp, X1, lane, nullptr,
                                 [] { lds_barrier(); });
     }
     lds_barrier();
