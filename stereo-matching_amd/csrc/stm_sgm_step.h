@@ -296,6 +296,37 @@ __device__ __forceinline__ int half_min_i32(int v) {
   return v;
 }
 
+// Two such minima at once (TYPE: f32 or i32), interleaved so that one's wait states are the
+// other's instructions; a leading s_nop covers a VALU write of the inputs just before.
+#define STM_HALF_MIN2(TYPE, a, b)                                                                     \
+  do {                                                                                                \
+    unsigned ta_, tb_;                                                                                \
+    asm("s_nop 1\n\t"                                                                                 \
+        "v_min_" TYPE "_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"            \
+        "v_min_" TYPE "_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"            \
+        "s_nop 0\n\t"                                                                                 \
+        "v_min_" TYPE "_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"            \
+        "v_min_" TYPE "_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"            \
+        "s_nop 0\n\t"                                                                                 \
+        "v_min_" TYPE "_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"                \
+        "v_min_" TYPE "_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"                \
+        "s_nop 0\n\t"                                                                                 \
+        "v_min_" TYPE "_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"                     \
+        "v_min_" TYPE "_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"                     \
+        "s_nop 0\n\t"                                                                                 \
+        "v_mov_b32 %2, %0\n\t"                                                                        \
+        "v_mov_b32 %3, %1\n\t"                                                                        \
+        "s_nop 0\n\t"                                                                                 \
+        "v_permlane16_swap_b32 %2, %0\n\t"                                                            \
+        "v_permlane16_swap_b32 %3, %1\n\t"                                                            \
+        "s_nop 0\n\t"                                                                                 \
+        "v_min_" TYPE " %0, %0, %2\n\t"                                                               \
+        "v_min_" TYPE " %1, %1, %3"                                                                    \
+        : "+v"(a), "+v"(b), "=&v"(ta_), "=&v"(tb_));                                                  \
+  } while (0)
+__device__ __forceinline__ void half_min2_f32(float &a, float &b) { STM_HALF_MIN2("f32", a, b); }
+__device__ __forceinline__ void half_min2_i32(int &a, int &b) { STM_HALF_MIN2("i32", a, b); }
+
 // One step for both halves (semiglobal.cpp:129-157).  `pen` holds the penalties P2' of the
 // lane's half, one per lane of each 16-lane row (both rows of a half hold the same sixteen);
 // PEN_LANE selects this step's.

@@ -1676,11 +1676,79 @@ __device__ __forceinline__ void h2_pair(const H2Pair &K, const Row<4> (&E)[4], i
   Row<4> pf = E[0];
   Row<4> pi = NA < kT ? E[3] : E[1];
   using std::integral_constant;
+  // The update of one slot, S = (S + F) + I; `acc` is the slot's sum as read from the sum tile
+  // (pair 0: nothing to read).  Pair 3 leaves the result in `acc` for `finish2`.
+  auto update = [&](auto s_, Row<4> &acc) {
+    constexpr int s = decltype(s_)::value;
+    if (PHASE == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc.v[j] = 0.0f;
+    }
+    f32x2 lo = f32x2{acc.v[0], acc.v[1]} + f32x2{LF[s].v[0], LF[s].v[1]};
+    f32x2 hi = f32x2{acc.v[2], acc.v[3]} + f32x2{LF[s].v[2], LF[s].v[3]};
+    if (run_inv) {
+      const f32x2 lo2 = lo + f32x2{LI[s].v[0], LI[s].v[1]};
+      const f32x2 hi2 = hi + f32x2{LI[s].v[2], LI[s].v[3]};
+      const bool r = PHASE < 2 || (s < NA ? run0 : run1);
+      lo = r ? lo2 : lo;
+      hi = r ? hi2 : hi;
+    }
+    acc.v[0] = lo.x; acc.v[1] = lo.y; acc.v[2] = hi.x; acc.v[3] = hi.y;
+    if (PHASE < 3) h2_lds_store(St, addr(s_), acc);
+  };
+  // Pair 3: the results of two slots leave -- the sums and / or their winners.  Winner takes
+  // all per half (src/winners_take_all.cu:21-40): strict-'<' scan in register order, then the
+  // lowest lane of the half among those holding its minimum; a NaN at d = 0 wins, as in the
+  // reference scan.  Without leaving the vector unit: the lanes holding the half's minimum
+  // offer their index, the others INT_MAX, a NaN at d = 0 offers -1; minimum over the half.
+  auto finish2 = [&](auto sa_, const Row<4> &ra, auto sb_, const Row<4> &rb) {
+    if constexpr (PHASE == 3) {
+      constexpr int sa = decltype(sa_)::value, sb = decltype(sb_)::value;
+      const int d0 = hl16 >> 2;
+      const int pa = sa < NA ? K.pix0 + sa * pstep : K.pix1 + (sa - NA) * pstep;
+      const int pb = sb < NA ? K.pix0 + sb * pstep : K.pix1 + (sb - NA) * pstep;
+      const unsigned qa = (unsigned)((y0 + (pa >> 3)) * W + (x0 + (pa & (kT - 1))));  // < H * W
+      const unsigned qb = (unsigned)((y0 + (pb >> 3)) * W + (x0 + (pb & (kT - 1))));
+      if (FINAL != 2) {
+        store_row<4, true>(out, (size_t)qa, 128, d0, ra);
+        store_row<4, true>(out, (size_t)qb, 128, d0, rb);
+      }
+      if (FINAL != 0) {
+        float ba = __builtin_inff(), bb = __builtin_inff();
+        int ia = d0, ib = d0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (ra.v[j] < ba) { ba = ra.v[j]; ia = d0 + j; }
+          if (rb.v[j] < bb) { bb = rb.v[j]; ib = d0 + j; }
+        }
+        float ma = ba, mb = bb;
+        half_min2_f32(ma, mb);
+        int ka = ba == ma ? ia : 0x7fffffff, kb = bb == mb ? ib : 0x7fffffff;
+        if (hl16 == 0 && ra.v[0] != ra.v[0]) ka = -1;
+        if (hl16 == 0 && rb.v[0] != rb.v[0]) kb = -1;
+        half_min2_i32(ka, kb);
+        if ((lane & 31) == 0) {
+          disp[qa] = ka < 0 ? 0 : ka;
+          disp[qb] = kb < 0 ? 0 : kb;
+        }
+      }
+    }
+  };
+  auto sum_of = [&](auto s_) {
+    Row<4> r;
+    if (PHASE != 0) r = h2_lds_row(St, addr(s_));
+    else r = E[0];  // (unused: any defined value)
+    return r;
+  };
   if (run_inv) {
     // Slot s of the forward chain together with slot 7 - s of the inverse chain
-    // (sgm_step_h2x2); the cost rows of the next two slots are requested first.
+    // (sgm_step_h2x2); the cost rows of the next two slots are requested first.  From the
+    // fifth step on both results of two slots exist (s and 7 - s): their update runs between
+    // the steps, its LDS round trip under the next step's arithmetic -- after `between`, which
+    // therefore sits in the middle of the chains.
     Row<4> cf = h2_lds_row(Ct, addr(integral_constant<int, 0>()));
     Row<4> ci = h2_lds_row(Ct, addr(integral_constant<int, kT - 1>()));
+    Row<4> sa, sb;  // the sums of the two slots updated next
     auto both = [&](auto s_) {
       constexpr int s = decltype(s_)::value, r = kT - 1 - s;
       if constexpr (PHASE >= 2 && s == NA && s > 0) {
@@ -1694,17 +1762,34 @@ __device__ __forceinline__ void h2_pair(const H2Pair &K, const Row<4> (&E)[4], i
         cfn = h2_lds_row(Ct, addr(integral_constant<int, s + 1>()));
         cin = h2_lds_row(Ct, addr(integral_constant<int, r - 1>()));
       }
+      if constexpr (s == kT / 2) {
+        between();
+        sa = sum_of(integral_constant<int, s>());
+        sb = sum_of(integral_constant<int, r>());
+      }
       sgm_step_h2x2<s, 8 + r>(pf, cf, pi, ci, pen, X, XI);
       LF[s] = pf;
       LI[r] = pi;
       cf = cfn;
       ci = cin;
+      if constexpr (s >= kT / 2) {
+        update(integral_constant<int, s>(), sa);
+        update(integral_constant<int, r>(), sb);
+        finish2(integral_constant<int, s>(), sa, integral_constant<int, r>(), sb);
+        if constexpr (s < kT - 1) {
+          sa = sum_of(integral_constant<int, s + 1>());
+          sb = sum_of(integral_constant<int, r - 1>());
+        }
+      }
     };
     both(integral_constant<int, 0>()); both(integral_constant<int, 1>());
     both(integral_constant<int, 2>()); both(integral_constant<int, 3>());
     both(integral_constant<int, 4>()); both(integral_constant<int, 5>());
     both(integral_constant<int, 6>()); both(integral_constant<int, 7>());
+    if (PHASE == 0) exit_f = LF[kT - 1];  // the rightward state where the lane's row leaves the tile
   } else {
+    between();
+    Row<4> sa = sum_of(integral_constant<int, 0>()), held = sa;
     auto fstep = [&](auto s_) {
       constexpr int s = decltype(s_)::value;
       if constexpr (PHASE >= 2 && s == NA && s > 0) {
@@ -1713,77 +1798,25 @@ __device__ __forceinline__ void h2_pair(const H2Pair &K, const Row<4> (&E)[4], i
       const Row<4> c = h2_lds_row(Ct, addr(s_));
       pf = sgm_step_h2<s>(pf, c, pen, X);
       LF[s] = pf;
+      if constexpr (PHASE == 3) {  // results leave two at a time
+        if constexpr (s % 2 == 0) {
+          update(s_, sa);
+          held = sa;
+        } else {
+          update(s_, sa);
+          finish2(integral_constant<int, s - 1>(), held, s_, sa);
+        }
+      } else {
+        update(s_, sa);
+      }
+      if constexpr (s < kT - 1) sa = sum_of(integral_constant<int, s + 1>());
     };
     fstep(integral_constant<int, 0>()); fstep(integral_constant<int, 1>());
     fstep(integral_constant<int, 2>()); fstep(integral_constant<int, 3>());
     fstep(integral_constant<int, 4>()); fstep(integral_constant<int, 5>());
     fstep(integral_constant<int, 6>()); fstep(integral_constant<int, 7>());
+    if (PHASE == 0) exit_f = LF[kT - 1];
   }
-  if (PHASE == 0) exit_f = LF[kT - 1];  // the rightward state where the lane's row leaves the tile
-  between();
-  // The update, four slots at a time: their sums are requested together (the compiler cannot
-  // move an LDS read above the previous slot's write -- it does not know that slots never
-  // alias -- and a read's latency per slot would be most of the update).
-  auto update4 = [&](auto base_) {
-    constexpr int s0 = decltype(base_)::value;
-    Row<4> acc[4];
-    int a[4];
-    a[0] = addr(integral_constant<int, s0>());
-    a[1] = addr(integral_constant<int, s0 + 1>());
-    a[2] = addr(integral_constant<int, s0 + 2>());
-    a[3] = addr(integral_constant<int, s0 + 3>());
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (PHASE == 0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i].v[j] = 0.0f;
-      } else {
-        acc[i] = h2_lds_row(St, a[i]);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int s = s0 + i;
-      f32x2 lo = f32x2{acc[i].v[0], acc[i].v[1]} + f32x2{LF[s].v[0], LF[s].v[1]};
-      f32x2 hi = f32x2{acc[i].v[2], acc[i].v[3]} + f32x2{LF[s].v[2], LF[s].v[3]};
-      if (run_inv) {
-        const f32x2 lo2 = lo + f32x2{LI[s].v[0], LI[s].v[1]};
-        const f32x2 hi2 = hi + f32x2{LI[s].v[2], LI[s].v[3]};
-        const bool r = PHASE < 2 || (s < NA ? run0 : run1);
-        lo = r ? lo2 : lo;
-        hi = r ? hi2 : hi;
-      }
-      acc[i].v[0] = lo.x; acc[i].v[1] = lo.y; acc[i].v[2] = hi.x; acc[i].v[3] = hi.y;
-      if (PHASE < 3) {
-        h2_lds_store(St, a[i], acc[i]);
-      } else {
-        const int pix = s < NA ? K.pix0 + s * pstep : K.pix1 + (s - NA) * pstep;
-        const unsigned q = (unsigned)((y0 + (pix >> 3)) * W + (x0 + (pix & (kT - 1))));  // < H * W
-        const int d0 = hl16 >> 2;
-        if (FINAL != 2) store_row<4, true>(out, (size_t)q, 128, d0, acc[i]);
-        if (FINAL != 0) {
-          // Winner takes all per half (src/winners_take_all.cu:21-40): strict-'<' scan in
-          // register order, then the lowest lane of the half among those holding its minimum;
-          // a NaN at d = 0 wins, as in the reference scan.
-          float best = __builtin_inff();
-          int idx = d0;
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (acc[i].v[j] < best) { best = acc[i].v[j]; idx = d0 + j; }
-          // ... without leaving the vector unit: the lanes holding the half's minimum offer
-          // their index, the others INT_MAX; a NaN at d = 0 offers -1; minimum over the half.
-          const float m = half_min_f32(best);
-          int key = best == m ? idx : 0x7fffffff;
-          if (hl16 == 0 && acc[i].v[0] != acc[i].v[0]) key = -1;
-          key = half_min_i32(key);
-          const int win = key < 0 ? 0 : key;
-          if ((lane & 31) == 0) disp[q] = win;
-        }
-      }
-    }
-  };
-  update4(integral_constant<int, 0>());
-  update4(integral_constant<int, 4>());
 }
 
 // The pair with the wave's slot count as a constant (the diagonal pairs change segment at
