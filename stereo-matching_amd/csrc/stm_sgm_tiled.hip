@@ -1558,15 +1558,18 @@ struct TileRowWalk {
   }
 };
 
-// A tile's terms of the entry addresses.
+// A tile's terms of the entry addresses; real = false: the tile is not interior, its entry
+// states are not used and every lane reads the same valid dummy row instead (`row`).
 struct H2TileBase {
   const float *row, *col;
+  bool real;
 };
 template <typename Walk>
 __device__ __forceinline__ H2TileBase h2_tile_base(float *ws, const TiledGeom &G, const Walk &t) {
   H2TileBase T;
   T.row = ws + G.rowb_off + (long long)t.b * G.rowb_img + (long long)(t.trow * G.W + t.tcol * kT) * G.D;
   T.col = ws + G.colb_off + (long long)t.b * G.colb_img + (long long)(t.tcol * G.H + t.trow * kT) * G.D;
+  T.real = true;
   return T;
 }
 
@@ -1574,7 +1577,9 @@ template <int N>
 __device__ __forceinline__ void h2_load_entries(Row<4> (&E)[4], const H2Pair &K, const H2TileBase &T, int d0) {
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const float *p = ((K.eoff[i] & 1) ? T.row : T.col) + (K.eoff[i] & ~1);
+    // (the offsets are relative to an interior tile's terms: added to anything else they may
+    // leave the workspace -- e.g. by -(H + 1) rows of D for a tall image)
+    const float *p = T.real ? ((K.eoff[i] & 1) ? T.row : T.col) + (K.eoff[i] & ~1) : T.row;
     E[i] = load_row<4, true>(p, 0, 128, d0);
   }
 }
@@ -1949,9 +1954,10 @@ __global__ __launch_bounds__(4 * 64, 2) void sgm_tile_h2_kernel(const float *__r
   };
   auto entry_base = [&](const TileRowWalk &t) {
     H2TileBase T = h2_tile_base(ws, G, t);
-    if (!interior(t)) {  // valid dummy addresses: this image's first border row, far enough in
-      T.row = ws + G.rowb_off + (long long)t.b * G.rowb_img + (long long)(G.W + kT) * D;
+    if (!interior(t)) {  // a valid dummy address: the first border row of the workspace
+      T.row = ws + G.rowb_off;
       T.col = T.row;
+      T.real = false;
     }
     return T;
   };
@@ -2112,7 +2118,13 @@ int run_tiled(const float *cost, const float *left, float *out, int32_t *disp, c
   const TiledGeom &G = plan.G;
   if (hipMemsetAsync(ws, 0, plan.zero_bytes, s) != hipSuccess)
     return fail(STM_EHIP, "stm_sgm_f32 (tiled): hipMemsetAsync failed");
-  {
+#ifdef STM_TILE_STAMPS
+  // diagnostic build only: leave out the walks (1), the sweeps (2), the tiles (4)
+  const int skip = getenv("STM_TILED_SKIP") ? atoi(getenv("STM_TILED_SKIP")) : 0;
+#else
+  constexpr int skip = 0;
+#endif
+  if (!(skip & 1)) {
     HwalkArgs A;
     A.G = G; A.p1 = p1; A.p2 = p2; A.dlim = dlim;
     A.only_left = VPL == 2;
@@ -2122,7 +2134,7 @@ int run_tiled(const float *cost, const float *left, float *out, int32_t *disp, c
     int rc = check_launch("stm_sgm_f32 (tiled: horizontal walks)");
     if (rc != STM_OK) return rc;
   }
-  for (int up = 0; up < 2; ++up) {
+  for (int up = 0; up < 2 && !(skip & 2); ++up) {
     for (int b0 = 0; b0 < batch; b0 += plan.group) {
       SweepArgs A;
       A.G = G; A.p1 = p1; A.p2 = p2; A.dlim = dlim; A.b0 = b0; A.status_off = plan.status_off;
@@ -2138,6 +2150,7 @@ int run_tiled(const float *cost, const float *left, float *out, int32_t *disp, c
       if (rc != STM_OK) return rc;
     }
   }
+  if (skip & 4) return STM_OK;
   {
     TileArgs A;
     A.G = G; A.p1 = p1; A.p2 = p2; A.dlim = dlim; A.true_paths = true_paths;

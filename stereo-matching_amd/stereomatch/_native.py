@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstereomatch_hip.so")
+# (STM_LIB_PATH: another build of the same library, for development probes such as tools/_probe)
+LIB_PATH = os.environ.get("STM_LIB_PATH") or os.path.join(_HERE, "libstereomatch_hip.so")
 
 ABI_VERSION = 1
 

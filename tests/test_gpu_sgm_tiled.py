@@ -6,6 +6,8 @@ through global mailboxes), widths and heights that are not multiples of the tile
 wave's column count, wide and tall images (the reference's re-walked and skipped inverse
 diagonals), every supported disparity count, batches that need more than one
 sweep launch, the corrected-algorithm options and the fused winner-takes-all."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -94,3 +96,48 @@ def test_tiled_form_is_refused_where_it_does_not_apply(device):
     a = stereomatch.aggregation.Semiglobal(form="tiled")(_gpu(C, device), _gpu(image, device))
     b = stereomatch.aggregation.Semiglobal(form="paired")(_gpu(C, device), _gpu(image, device))
     assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+def _fuzz_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for _ in range(n):
+        D = int(rng.choice([64, 128, 128, 128, 256]))
+        H, W = int(rng.integers(1, 120)), int(rng.integers(1, 180))
+        if rng.random() < 0.3:  # enough interior tiles for the two-pixels-per-wave forms
+            H, W = int(rng.integers(24, 120)), int(rng.integers(24, 180))
+        B = int(rng.integers(1, 5))
+        cases.append((H, W, D, B, str(rng.choice(["float", "ties", "last"])),
+                      str(rng.choice(["reference", "reference", "hirschmuller"])), bool(rng.random() < 0.3)))
+    return cases
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_tiled_fuzz_against_paired(device, seed):
+    """Random shapes, batches and options: the tiled form against the paired form (which the
+    other tests hold against the oracle), sum volume and fused disparities, bit for bit."""
+    import stereomatch
+    for H, W, D, B, kind, paths, full_min in _fuzz_cases(25, seed):
+        rng = np.random.default_rng(H * 7919 + W * 31 + D + B)
+        C = np.stack([_random_volume(rng, H, W, D, kind) for _ in range(B)])
+        image = rng.integers(0, 6, size=(B, H, W)).astype(np.float32)
+        Cg, Ig = _gpu(C, device), _gpu(image, device)
+        kw = dict(penalty1=0.25, penalty2=2.0, paths=paths, full_min=full_min)
+        t = stereomatch.aggregation.Semiglobal(form="tiled", **kw)
+        p = stereomatch.aggregation.Semiglobal(form="paired", **kw)
+        what = "H=%d W=%d D=%d B=%d %s %s full_min=%s" % (H, W, D, B, kind, paths, full_min)
+        if os.environ.get("STM_FUZZ_VERBOSE"):
+            print(what, flush=True)
+        St = t(Cg, Ig)
+        if os.environ.get("STM_FUZZ_VERBOSE"):
+            torch.cuda.synchronize()
+            print("  tiled sum done", flush=True)
+        Sp = p(Cg, Ig)
+        if os.environ.get("STM_FUZZ_VERBOSE"):
+            torch.cuda.synchronize()
+            print("  paired sum done", flush=True)
+        assert t.status() == 0, what
+        assert torch.equal(St.view(torch.int32), Sp.view(torch.int32)), "sum volume: " + what
+        _, dt = t.aggregate_and_reduce(Cg, Ig)
+        _, dp_ = p.aggregate_and_reduce(Cg, Ig)
+        assert torch.equal(dt, dp_), "fused disparities: " + what
