@@ -104,8 +104,13 @@ def _fuzz_cases(n, seed):
     for _ in range(n):
         D = int(rng.choice([64, 128, 128, 128, 256]))
         H, W = int(rng.integers(1, 120)), int(rng.integers(1, 180))
-        if rng.random() < 0.3:  # enough interior tiles for the two-pixels-per-wave forms
+        u = rng.random()
+        if u < 0.3:    # enough interior tiles for the two-pixels-per-wave forms
             H, W = int(rng.integers(24, 120)), int(rng.integers(24, 180))
+        elif u < 0.4:  # very tall
+            H, W = int(rng.integers(100, 260)), int(rng.integers(1, 40))
+        elif u < 0.5:  # very wide
+            H, W = int(rng.integers(1, 40)), int(rng.integers(100, 400))
         B = int(rng.integers(1, 5))
         cases.append((H, W, D, B, str(rng.choice(["float", "ties", "last"])),
                       str(rng.choice(["reference", "reference", "hirschmuller"])), bool(rng.random() < 0.3)))
