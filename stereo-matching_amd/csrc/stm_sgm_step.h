@@ -275,29 +275,8 @@ __device__ __forceinline__ float half_min_f32(float v) {
   return v;
 }
 
-// The same for integers (the winner's index in the fused winner-takes-all).
-__device__ __forceinline__ int half_min_i32(int v) {
-  int t;
-  asm("s_nop 1\n\t"
-      "v_min_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_min_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_min_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_min_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_mov_b32 %1, %0\n\t"
-      "s_nop 1\n\t"
-      "v_permlane16_swap_b32 %1, %0\n\t"
-      "s_nop 1\n\t"
-      "v_min_i32 %0, %0, %1"
-      : "+v"(v), "=&v"(t));
-  return v;
-}
-
-// Two such minima at once (TYPE: f32 or i32), interleaved so that one's wait states are the
-// other's instructions; a leading s_nop covers a VALU write of the inputs just before.
+// Two such minima at once (TYPE: f32, or i32 for the winner's index in the fused
+// winner-takes-all), interleaved so that one's wait states are the other's instructions; a leading s_nop covers a VALU write of the inputs just before.
 #define STM_HALF_MIN2(TYPE, a, b)                                                                     \
   do {                                                                                                \
     unsigned ta_, tb_;                                                                                \

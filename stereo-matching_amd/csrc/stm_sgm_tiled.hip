@@ -1643,9 +1643,6 @@ __device__ __forceinline__ void h2_lds_store(float *tile, int byte_addr, const R
   *reinterpret_cast<v4f *>(reinterpret_cast<char *>(tile) + byte_addr) = q;
 }
 
-template <int S>
-struct H2Slot {};
-
 // One pair of an interior tile for one wave (two lines): both chains, `between` (the barrier
 // behind which the previous pair's update is complete), the update S = (S + F) + I.
 template <int PHASE, int NA, int FINAL, typename Between>
