@@ -267,9 +267,9 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
     }
     ++T;
   };
-  // Parks what the fetch at time T - 1 brought.
-  auto park = [&](int buf, const float4 (&regs)[LP]) {
-    const int set = (T - 1) & (G - 1);
+  // Parks what the fetch for time `when` brought.
+  auto park = [&](int buf, const float4 (&regs)[LP], int when) {
+    const int set = when & (G - 1);
 #pragma unroll
     for (int u = 0; u < LP; ++u) {
       const int j = u * PPI + lane / LPG, part = lane % LPG;
@@ -283,18 +283,23 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
     wave_lds_handoff();
   }
 
-  float4 regs[LP];
-  fetch(regs);
-  park(0, regs);
+  // Two register sets: the pieces of block blk + 1 wait in one (requested during block blk - 1)
+  // while those of block blk + 2 are requested into the other -- a block takes about a
+  // microsecond, a load from HBM up to two or three, and with one block of lead every block of
+  // a lone workgroup (a single pair: one per CU) waited for its loads.
+  float4 regs_a[LP], regs_b[LP];
+  fetch(regs_a);
+  park(0, regs_a, 0);
+  fetch(regs_b);
   wave_lds_handoff();  // init[] and tile[0] are read by other lanes below
   float hist[O];
 #pragma unroll
   for (int j = 0; j < O; ++j) hist[j] = inf;
   float prev = inf;
   const int nblocks = W + 15;
-  for (int blk = 0; blk < nblocks; ++blk) {
+  auto block = [&](int blk, float4 (&freg)[LP], const float4 (&preg)[LP]) {
     const int cur = blk & 1;
-    fetch(regs);  // the next block's pieces: in flight while this block computes
+    fetch(freg);  // the pieces of block blk + 2: in flight while this and the next block compute
     const int q = blk - v;
     const int col = v + 16 * (q >> 4);
     const int d0 = O * (q & 15);
@@ -389,8 +394,12 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
         }
       }
     }
-    park(G == 1 ? cur ^ 1 : 0, regs);
+    park(G == 1 ? cur ^ 1 : 0, preg, blk + 1);
     wave_lds_handoff();  // the parked pieces (and pbuf) change hands between iterations
+  };
+  for (int blk = 0; blk < nblocks; blk += 2) {
+    block(blk, regs_a, regs_b);
+    if (blk + 1 < nblocks) block(blk + 1, regs_b, regs_a);
   }
   // Flush the final costs (fin[] was written by the lanes that own the last column).
   float *rowfin = rowfin_all + ((size_t)b * H + (rowok ? row : 0)) * D;
