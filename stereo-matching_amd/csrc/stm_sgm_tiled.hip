@@ -2210,12 +2210,14 @@ bool sgm_tiled_selected(int H, int W, int D, int batch, int flags) {
   // Measured on MI355X (tools/sgm_forms.py): the tiled form wins where the volume traffic it
   // saves outweighs its fixed costs per image row and per tile, i.e. for wide disparity ranges
   // with enough columns in the batch to keep the row sweeps' column strips on most CUs:
-  // D = 256: from 3 pairs at 1080p (4.0 against 5.8 ms per pair at 8-16 pairs; 8.0 against 6.0 ms
-  // for a single pair); D = 128: 7-9 % ahead on large batches (Teddy x 256: 51.7 against 55.6 ms);
-  // D = 64: the paired form is 1.4x faster and keeps the job.
+  // D = 256: from 2 pairs at 1080p (10.8 against 11.3 ms for two, 4.5 against 5.7 ms per pair for
+  // three, 4.0 against 5.8 at 8-16; 8.0 against 5.9 ms for a single pair); D = 128: from ~28 Teddy
+  // pairs (5.6 against 5.3 ms at 24, 6.2 against 7.2 at 32, 42 against 55 at 256); D = 64: the paired
+  // form is 1.4x faster and keeps the job.
   const int cus = device_cus();
   const int strip_cols = kSweepWaves * sweep_cw(D / 64);
-  return D >= 128 && (long long)batch * W * 2 >= (long long)cus * strip_cols && H >= 64;
+  const long long need = (long long)cus * strip_cols * (D == 256 ? 9 : 15);  // tenths
+  return D >= 128 && (long long)batch * W * 2 * 10 >= need && H >= 64;
 }
 
 size_t sgm_tiled_workspace_bytes(int H, int W, int D, int batch, int flags) {
