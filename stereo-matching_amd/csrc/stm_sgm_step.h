@@ -305,6 +305,7 @@ __device__ __forceinline__ float half_min_f32(float v) {
   } while (0)
 __device__ __forceinline__ void half_min2_f32(float &a, float &b) { STM_HALF_MIN2("f32", a, b); }
 __device__ __forceinline__ void half_min2_i32(int &a, int &b) { STM_HALF_MIN2("i32", a, b); }
+#undef STM_HALF_MIN2
 
 // One step for both halves (semiglobal.cpp:129-157).  `pen` holds the penalties P2' of the
 // lane's half, one per lane of each 16-lane row (both rows of a half hold the same sixteen);

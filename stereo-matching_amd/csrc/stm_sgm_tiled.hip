@@ -1617,8 +1617,8 @@ __device__ __forceinline__ int h2_count_class(const TiledGeom &G, int x0, int y0
 
 // Penalties of the lane's line: lane i of every 16-lane row holds the one of slot i & 7 on
 // the F chain (i < 8: the step from its predecessor) or the I chain (from its successor).
-template <int PHASE, int NA>
-__device__ __forceinline__ float h2_penalties(const H2Pair &K, const float *Ip, float p1, float p2, int lane) {
+template <int PHASE>
+__device__ __forceinline__ float h2_penalties(const H2Pair &K, int NA, const float *Ip, float p1, float p2, int lane) {
   constexpr int dx = PhaseDir<PHASE>::dx, dy = PhaseDir<PHASE>::dy;
   constexpr int pstep = dy * kT + dx;
   const int s = lane & 7;
@@ -1648,7 +1648,7 @@ __device__ __forceinline__ void h2_lds_store(float *tile, int byte_addr, const R
 template <int PHASE, int NA, int FINAL, typename Between>
 __device__ __forceinline__ void h2_pair(const H2Pair &K, const Row<4> (&E)[4], int cls, int w, int half, const TiledGeom &G,
                                         int true_paths, const float *Ct,
-                                        float *St, const float *Ip, float p1, float p2, StepCtxH2 &X, int lane,
+                                        float *St, float pen, StepCtxH2 &X, int lane,
                                         int hl16, int W, int x0, int y0, float *__restrict__ out,
                                         int32_t *__restrict__ disp, Row<4> &exit_f, Between between) {
   constexpr int dx = PhaseDir<PHASE>::dx, dy = PhaseDir<PHASE>::dy;
@@ -1668,7 +1668,6 @@ __device__ __forceinline__ void h2_pair(const H2Pair &K, const Row<4> (&E)[4], i
     run0 = seg_counts<PHASE>(s0, x0, y0, G, true_paths).inv != 0;
     run1 = seg_counts<PHASE>(s1, x0, y0, G, true_paths).inv != 0;
   }
-  const float pen = h2_penalties<PHASE, NA>(K, Ip, p1, p2, lane);
   const int a0 = K.pix0 * kPixBytes + hl16, a1 = K.pix1 * kPixBytes + hl16;
   auto addr = [&](auto s_) {  // LDS byte address of slot s (the slot part is an immediate)
     constexpr int s = decltype(s_)::value;
@@ -1825,13 +1824,13 @@ __device__ __forceinline__ void h2_pair(const H2Pair &K, const Row<4> (&E)[4], i
 // slot w + 1, wave 3 at slot 4).
 template <int PHASE, int FINAL, typename Between>
 __device__ __forceinline__ void h2_pair_w(int w, int half, const H2Pair &K, const Row<4> (&E)[4], int cls,
-                                          const TileArgs &P, const float *Ct, float *St, const float *Ip,
+                                          const TileArgs &P, const float *Ct, float *St, float pen,
                                           StepCtxH2 &X, int lane, int hl16, int x0, int y0,
                                           float *__restrict__ out, int32_t *__restrict__ disp, Row<4> &exit_f,
                                           Between between) {
 #define STM_H2_PAIR(NA)                                                                              \
-  h2_pair<PHASE, NA, FINAL>(K, E, cls, w, half, P.G, P.true_paths, Ct, St, Ip, P.p1, P.p2, X, lane, hl16, \
-                            P.G.W, x0, y0, out, disp, exit_f, between)
+  h2_pair<PHASE, NA, FINAL>(K, E, cls, w, half, P.G, P.true_paths, Ct, St, pen, X, lane, hl16, P.G.W, x0, y0, \
+                            out, disp, exit_f, between)
   if constexpr (PHASE < 2) {
     STM_H2_PAIR(kT);
   } else {
@@ -2004,17 +2003,24 @@ __global__ __launch_bounds__(4 * 64, 2) void sgm_tile_h2_kernel(const float *__r
       h2_load_entries<4>(Ec, K2, T, d0);
       h2_load_entries<4>(Ed, K3, T, d0);
       prefetch_cost(next_t);
-      h2_pair_w<0, FINAL>(w, half, K0, Ea, 1, P, Ct, St, Ip, X, lane, hl16, x0, y0, out, disp, carry, [] {});
+      // The penalties of all four pairs now: four independent division sequences instead of one
+      // in front of every pair's chains.
+      const int na = h2_na(2, w);
+      const float pen0 = h2_penalties<0>(K0, kT, Ip, P.p1, P.p2, lane);
+      const float pen1 = h2_penalties<1>(K1, kT, Ip, P.p1, P.p2, lane);
+      const float pen2 = h2_penalties<2>(K2, na, Ip, P.p1, P.p2, lane);
+      const float pen3 = h2_penalties<3>(K3, na, Ip, P.p1, P.p2, lane);
+      h2_pair_w<0, FINAL>(w, half, K0, Ea, 1, P, Ct, St, pen0, X, lane, hl16, x0, y0, out, disp, carry, [] {});
       have_carry = true;
       store_row<4, true>(exits + (size_t)(2 * w + half) * D, 0, D, d0, carry);
-      h2_pair_w<1, FINAL>(w, half, K1, Eb, 1, P, Ct, St, Ip, X, lane, hl16, x0, y0, out, disp, unused,
+      h2_pair_w<1, FINAL>(w, half, K1, Eb, 1, P, Ct, St, pen1, X, lane, hl16, x0, y0, out, disp, unused,
                           [] { lds_barrier(); });
       h2_load_entries<2>(E0, K0, entry_base(next_t), d0);
       h2_load_entries<2>(E1, K1, entry_base(next_t), d0);
-      h2_pair_w<2, FINAL>(w, half, K2, Ec, cls2, P, Ct, St, Ip, X, lane, hl16, x0, y0, out, disp, unused,
+      h2_pair_w<2, FINAL>(w, half, K2, Ec, cls2, P, Ct, St, pen2, X, lane, hl16, x0, y0, out, disp, unused,
                           [] { lds_barrier(); });
       STM_STAMP(3);
-      h2_pair_w<3, FINAL>(w, half, K3, Ed, cls3, P, Ct, St, Ip, X, lane, hl16, x0, y0, out, disp, unused,
+      h2_pair_w<3, FINAL>(w, half, K3, Ed, cls3, P, Ct, St, pen3, X, lane, hl16, x0, y0, out, disp, unused,
                           [&] { STM_STAMP(4); lds_barrier(); STM_STAMP(5); });
       STM_STAMP(6);
     } else {
