@@ -188,6 +188,16 @@ __device__ __forceinline__ void mbox_wait(const u64 *box, int D, int d0, unsigne
   }
 }
 
+// a or b, element by element (a conditional on the structs would select between their
+// addresses and put both in scratch memory).
+template <int VPL>
+__device__ __forceinline__ Row<VPL> pick_row(bool take_a, const Row<VPL> &a, const Row<VPL> &b) {
+  Row<VPL> r;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) r.v[j] = take_a ? a.v[j] : b.v[j];
+  return r;
+}
+
 // =====================================================================================
 // Row sweep: three directions per read of the cost volume.
 //
@@ -309,24 +319,36 @@ __global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float
   // recomputing 64-bit addresses every row is row time; at D = 256 the sweep is HBM-bound and
   // the two loops take the same time.
   if constexpr (H2) {
-    if (xa >= 1 && xa + CW <= W - 1) {
+    if (active) {
       static_assert(!H2 || CW == 4, "two columns per half-wave");
-      // ---- D = 128, interior wave: lanes 0-31 own columns xa, xa + 1, lanes 32-63 columns
-      // xa + 2, xa + 3, four disparities per lane; a row is two batches of three steps.
+      // ---- D = 128: lanes 0-31 own columns xa, xa + 1, lanes 32-63 columns xa + 2, xa + 3, four
+      // disparities per lane; a row is two batches of three steps.  A wave at an image border
+      // (`edge`: it holds column 0, column W - 1 or columns past it) additionally starts the
+      // paths that begin there (L = C), re-reads its last valid column for the missing ones and
+      // keeps their states to itself; a workgroup -- and through the hand-offs the whole sweep --
+      // runs at the pace of its slowest wave, which the one-pixel-per-wave loop below made the
+      // edge waves.
+      const bool edge = !(xa >= 1 && xa + CW <= W - 1);
       const int half = lane >> 5, hl = lane & 31, dh = hl * 4;
       const int vw = 2 * wv + half;
       constexpr int PFH = 2;  // cost rows in flight beyond the current one
       // Addresses are a wave-uniform base plus this lane's 32-bit offset (its half's first
       // column and its disparities).
       const unsigned loff = (unsigned)(half * 2 * D + dh);
+      const int col0 = xa + 2 * half;  // this half's columns: col0, col0 + 1
+      const unsigned lload0 = (unsigned)((imin(col0, W - 1) - xa) * D + dh);
+      const unsigned lload1 = (unsigned)((imin(col0 + 1, W - 1) - xa) * D + dh);
+      const bool valid0 = col0 < W, valid1 = col0 + 1 < W;
+      const bool start_a0 = col0 == 0;                             // a rightward path begins in image column 0
+      const bool start_b0 = col0 >= W - 1, start_b1 = col0 + 1 >= W - 1;  // a leftward one in column W - 1
       const long row_step = (long)(UP ? -1 : 1) * W * D;
       const float *cnext = cost + (size_t)(UP ? H - 1 : 0) * W * D + (size_t)xa * D;  // next row to fetch
       int t_next = 0;
       // Penalties: lane i of every 16-lane row serves column i / 3 (0, 1) of the row's half and
       // direction i % 3 (0 V, 1 A, 2 B).
       const int i16 = lane & 15;
-      const int pxh = xa + 2 * half + imin(i16 / 3, 1), pkh = i16 % 3;
-      const int pxsh = pkh == 1 ? pxh - 1 : (pkh == 2 ? pxh + 1 : pxh);
+      const int pxh = imin(col0 + imin(i16 / 3, 1), W - 1), pkh = i16 % 3;
+      const int pxsh = pkh == 1 ? (pxh > 0 ? pxh - 1 : 0) : (pkh == 2 ? imin(pxh + 1, W - 1) : pxh);
       const float *inext = image + (size_t)(UP ? H - 1 : 0) * W;
       const int istep = UP ? -W : W;
       Row<4> Vh[2], Ah[2], Bh[2], ch[PFH + 1][2];
@@ -334,14 +356,14 @@ __global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float
       auto refill = [&](Row<4> (&dst)[2], float &icur, float &iprev) {
         icur = inext[(unsigned)pxh];
         iprev = (t_next > 0 ? inext - istep : inext)[(unsigned)pxsh];
-        dst[0] = load_row<4, true, true>(cnext + loff, 0, D, 0);
-        dst[1] = load_row<4, true, true>(cnext + (loff + (unsigned)D), 0, D, 0);
+        dst[0] = load_row<4, true, true>(cnext + lload0, 0, D, 0);
+        dst[1] = load_row<4, true, true>(cnext + lload1, 0, D, 0);
         if (t_next < H - 1) { cnext += row_step; inext += istep; }
         ++t_next;
       };
       const bool colA_here = (xa & (kT - 1)) == 4, colB_here = (xa & (kT - 1)) == 0;  // x % 8 == 7 is xa + 3, == 0 is xa
       const int y_first = UP ? H - 1 : 0;
-      float *colA = colA_here ? colb_ptr(ws, G, b, UP ? 2 : 1, (xa + 3) >> 3, y_first) : nullptr;
+      float *colA = colA_here && xa + 3 < W ? colb_ptr(ws, G, b, UP ? 2 : 1, (xa + 3) >> 3, y_first) : nullptr;
       float *colB = colB_here ? colb_ptr(ws, G, b, UP ? 5 : 4, xa >> 3, y_first) : nullptr;
       const int col_step = UP ? -D : D;
       float *rowV = rowb_ptr(ws, G, b, UP ? 3 : 0, 0, xa);
@@ -389,6 +411,7 @@ __global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float
                 Vh[0] = st[0];
                 Ah[1] = st[1];
                 Bh[0] = st[2];
+                if (edge) Bh[0] = pick_row(start_b0, ch[u][0], Bh[0]);
               }
               leave(par, (unsigned)t);
               {  // V in column 1, A into column 0 and B into column 1 from what arrived
@@ -411,6 +434,10 @@ __global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float
                 Vh[1] = st[0];
                 Ah[0] = st[1];
                 Bh[1] = st[2];
+                if (edge) {
+                  Ah[0] = pick_row(start_a0, ch[u][0], Ah[0]);
+                  Bh[1] = pick_row(start_b1, ch[u][1], Bh[1]);
+                }
               }
             }
             if (sub && !dead && t + 1 < H) mbox_peek<4>(sub, D, dh, (unsigned)t, qa4);
@@ -418,9 +445,11 @@ __global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float
               float *r0 = rowV + (long long)(y >> 3) * W * D;
 #pragma unroll
               for (int j = 0; j < 2; ++j) {
-                store_row<4, true, true>(r0 + (loff + (unsigned)(j * D)), 0, D, 0, Vh[j]);
-                store_row<4, true, true>(r0 + kstride + (loff + (unsigned)(j * D)), 0, D, 0, Ah[j]);
-                store_row<4, true, true>(r0 + 2 * kstride + (loff + (unsigned)(j * D)), 0, D, 0, Bh[j]);
+                if (!edge || (j == 0 ? valid0 : valid1)) {
+                  store_row<4, true, true>(r0 + (loff + (unsigned)(j * D)), 0, D, 0, Vh[j]);
+                  store_row<4, true, true>(r0 + kstride + (loff + (unsigned)(j * D)), 0, D, 0, Ah[j]);
+                  store_row<4, true, true>(r0 + 2 * kstride + (loff + (unsigned)(j * D)), 0, D, 0, Bh[j]);
+                }
               }
             }
             if (colA) {
@@ -439,6 +468,9 @@ __global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float
       }
       return;
     }
+    // (a wave past the image only keeps the row barriers)
+    for (int t = 0; t < H; ++t) lds_barrier();
+    return;
   } else if (VPL <= 2 && xa >= 1 && xa + CW <= W - 1) {
     const long row_step = (long)(UP ? -1 : 1) * W * D;  // elements from one row to the next
     const float *cnext = cost + (size_t)(UP ? H - 1 : 0) * W * D + (size_t)xa * D + d0;  // this lane's part of the next row to fetch
@@ -1979,7 +2011,7 @@ __global__ __launch_bounds__(4 * 64, 2) void sgm_tile_h2_kernel(const float *__r
     }
     if (threadIdx.x < (kT + 2) * (kT + 2)) Ip[threadIdx.x] = ipre;
     Row<4> Ea[4], Eb[4];
-    Ea[0] = have_carry ? carry : E0[0];
+    Ea[0] = pick_row(have_carry, carry, E0[0]);
     Ea[1] = E0[1];
     Eb[0] = E1[0]; Eb[1] = E1[1];
     STM_STAMP(1);
