@@ -355,7 +355,7 @@ __global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float
       float ich[PFH + 1], iph[PFH + 1];
       auto refill = [&](Row<4> (&dst)[2], float &icur, float &iprev) {
         icur = inext[(unsigned)pxh];
-        iprev = (t_next > 0 ? inext - istep : inext)[(unsigned)pxsh];
+        iprev = (t_next > 0 && H > 1 ? inext - istep : inext)[(unsigned)pxsh];
         dst[0] = load_row<4, true, true>(cnext + lload0, 0, D, 0);
         dst[1] = load_row<4, true, true>(cnext + lload1, 0, D, 0);
         if (t_next < H - 1) { cnext += row_step; inext += istep; }
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float
     const int istep = UP ? -W : W;
     auto refill = [&](Row<VPL> (&dst)[CW], float &icur, float &iprev) {
       icur = inext[px];
-      iprev = (t_next > 0 ? inext - istep : inext)[pxs];
+      iprev = (t_next > 0 && H > 1 ? inext - istep : inext)[pxs];
 #pragma unroll
       for (int j = 0; j < CW; ++j) dst[j] = load_row<VPL, true, true>(cnext + j * D, 0, D, 0);
       if (t_next < H - 1) { cnext += row_step; inext += istep; }  // past the end: the last row again (unused)
@@ -1618,8 +1618,8 @@ __device__ __forceinline__ void h2_load_entries(Row<4> (&E)[4], const H2Pair &K,
 
 // How the inverse passes of a pair count inside a tile (seg_counts): 1 = every one once, 0 =
 // none at all (the reference never runs them there), 2 = some once and some not (per line),
-// -1 = the tile holds a diagonal that counts several times or before its forward pass: the
-// generic forms.
+// 3 = the tile holds the diagonal that counts several times or before its forward pass (the
+// update then repeats its additions per line).
 template <int PHASE>
 __device__ __forceinline__ int h2_count_class(const TiledGeom &G, int x0, int y0, int true_paths) {
   if (PHASE < 2 || true_paths) return 1;
@@ -1627,12 +1627,12 @@ __device__ __forceinline__ int h2_count_class(const TiledGeom &G, int x0, int y0
   if (PHASE == 2) {
     const int lo = x0 - y0 - (kT - 1), hi = x0 - y0 + (kT - 1);  // x - y over the tile
     if (e > 0) {
-      if (lo <= e && e <= hi) return -1;
+      if (lo <= e && e <= hi) return 3;
       if (lo >= 0 && hi <= e - 1) return 0;
       return (hi < 0 || lo > e) ? 1 : 2;
     }
     if (e < -1) {
-      if (lo <= e && e <= hi) return -1;
+      if (lo <= e && e <= hi) return 3;
       if (lo >= e + 1 && hi <= -1) return 0;
       return (hi < e || lo >= 0) ? 1 : 2;
     }
@@ -1640,7 +1640,7 @@ __device__ __forceinline__ int h2_count_class(const TiledGeom &G, int x0, int y0
   }
   if (e > 0) {
     const int lo = x0 + y0, hi = x0 + y0 + 2 * (kT - 1);  // x + y over the tile
-    if (lo <= G.H - 1 && G.H - 1 <= hi) return -1;
+    if (lo <= G.H - 1 && G.H - 1 <= hi) return 3;
     if (lo >= G.H && hi <= G.W - 1) return 0;
     return (hi < G.H - 1 || lo > G.W - 1) ? 1 : 2;
   }
@@ -1690,16 +1690,21 @@ __device__ __forceinline__ void h2_pair(const H2Pair &K, const Row<4> (&E)[4], i
   // cls (h2_count_class): 0 no inverse pass at all, 1 all of them, 2 per line and part
   const bool run_inv = cls != 0;
   bool run0 = true, run1 = true;
-  if (PHASE >= 2 && cls == 2) {
+  int pre0 = 0, pre1 = 0, inv0 = 1, inv1 = 1;  // seg_counts of the lane's two parts (cls >= 2)
+  if (PHASE >= 2 && cls >= 2) {
     H2Part q0, q1;
     bool restart_;
     h2_parts<PHASE>(w, half, q0, q1, restart_);
     Seg s0, s1;
     s0.ex = q0.ex; s0.ey = q0.ey; s0.n = q0.n;
     s1.ex = q1.ex; s1.ey = q1.ey; s1.n = q1.n;
-    run0 = seg_counts<PHASE>(s0, x0, y0, G, true_paths).inv != 0;
-    run1 = seg_counts<PHASE>(s1, x0, y0, G, true_paths).inv != 0;
+    const Counts c0 = seg_counts<PHASE>(s0, x0, y0, G, true_paths), c1 = seg_counts<PHASE>(s1, x0, y0, G, true_paths);
+    pre0 = c0.pre; inv0 = c0.inv;
+    pre1 = c1.pre; inv1 = c1.inv;
+    run0 = inv0 != 0;
+    run1 = inv1 != 0;
   }
+  const bool counted = PHASE >= 2 && cls == 3;
   const int a0 = K.pix0 * kPixBytes + hl16, a1 = K.pix1 * kPixBytes + hl16;
   auto addr = [&](auto s_) {  // LDS byte address of slot s (the slot part is an immediate)
     constexpr int s = decltype(s_)::value;
@@ -1717,14 +1722,35 @@ __device__ __forceinline__ void h2_pair(const H2Pair &K, const Row<4> (&E)[4], i
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc.v[j] = 0.0f;
     }
-    f32x2 lo = f32x2{acc.v[0], acc.v[1]} + f32x2{LF[s].v[0], LF[s].v[1]};
-    f32x2 hi = f32x2{acc.v[2], acc.v[3]} + f32x2{LF[s].v[2], LF[s].v[3]};
-    if (run_inv) {
-      const f32x2 lo2 = lo + f32x2{LI[s].v[0], LI[s].v[1]};
-      const f32x2 hi2 = hi + f32x2{LI[s].v[2], LI[s].v[3]};
-      const bool r = PHASE < 2 || (s < NA ? run0 : run1);
-      lo = r ? lo2 : lo;
-      hi = r ? hi2 : hi;
+    f32x2 lo = f32x2{acc.v[0], acc.v[1]}, hi = f32x2{acc.v[2], acc.v[3]};
+    const f32x2 ilo = f32x2{LI[s].v[0], LI[s].v[1]}, ihi = f32x2{LI[s].v[2], LI[s].v[3]};
+    if (counted) {
+      // S = ((S + [I x pre]) + F) + I x inv with the line's own counts (tile_add); the loop
+      // bounds are the larger of the two halves' (a half holds one line).
+      const int pre = s < NA ? pre0 : pre1, inv = s < NA ? inv0 : inv1;
+      const int pa = __builtin_amdgcn_readlane(pre, 0), pb = __builtin_amdgcn_readlane(pre, 32);
+      const int ia = __builtin_amdgcn_readlane(inv, 0), ib = __builtin_amdgcn_readlane(inv, 32);
+      for (int r = 0, n = pa > pb ? pa : pb; r < n; ++r) {
+        const f32x2 l2 = lo + ilo, h2 = hi + ihi;
+        lo = r < pre ? l2 : lo;
+        hi = r < pre ? h2 : hi;
+      }
+      lo = lo + f32x2{LF[s].v[0], LF[s].v[1]};
+      hi = hi + f32x2{LF[s].v[2], LF[s].v[3]};
+      for (int r = 0, n = ia > ib ? ia : ib; r < n; ++r) {
+        const f32x2 l2 = lo + ilo, h2 = hi + ihi;
+        lo = r < inv ? l2 : lo;
+        hi = r < inv ? h2 : hi;
+      }
+    } else {
+      lo = lo + f32x2{LF[s].v[0], LF[s].v[1]};
+      hi = hi + f32x2{LF[s].v[2], LF[s].v[3]};
+      if (run_inv) {
+        const f32x2 lo2 = lo + ilo, hi2 = hi + ihi;
+        const bool r = PHASE < 2 || (s < NA ? run0 : run1);
+        lo = r ? lo2 : lo;
+        hi = r ? hi2 : hi;
+      }
     }
     acc.v[0] = lo.x; acc.v[1] = lo.y; acc.v[2] = hi.x; acc.v[3] = hi.y;
     if (PHASE < 3) h2_lds_store(St, addr(s_), acc);
