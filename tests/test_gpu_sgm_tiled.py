@@ -111,6 +111,11 @@ def _fuzz_cases(n, seed):
             H, W = int(rng.integers(100, 260)), int(rng.integers(1, 40))
         elif u < 0.5:  # very wide
             H, W = int(rng.integers(1, 40)), int(rng.integers(100, 400))
+        elif u < 0.6:  # one to three rows or columns
+            if rng.random() < 0.5:
+                H = int(rng.integers(1, 4))
+            else:
+                W = int(rng.integers(1, 4))
         B = int(rng.integers(1, 5))
         cases.append((H, W, D, B, str(rng.choice(["float", "ties", "last"])),
                       str(rng.choice(["reference", "reference", "hirschmuller"])), bool(rng.random() < 0.3)))
