@@ -15,8 +15,10 @@ Workloads (BASELINE.json ``configs``):
   1080p  = configs[3]: 1080x1920, SSD(256) + SGM + WTA                    (reported under
            "also", with its own roofline: the HBM-roofline configuration)
 Multi-GPU: independent pairs are sharded over ranks (weak scaling: every rank runs the
-same batch size); the only collective is the final all_gather of the int32 disparity
-maps over RCCL, inside the timed step.
+same batch size) and their disparity maps stay on the GPU that computed them: no collective
+on the data path.  The last step's maps are all-gathered once over RCCL inside the timed
+region (--gather last, the default; --gather every does it after every step, overlapped with
+the next step's kernels; --gather none leaves it out).
 
 Rank 0 prints ONE JSON line.  ``roofline`` is for the semiglobal aggregation stage (the
 dominant kernels: one sgm_ckpt_kernel + four sgm_pair_kernel launches per step, the last
@@ -41,6 +43,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 FORCE_GATHER = False  # --rehearse-nccl: run the gather code path in a 1-rank RCCL group
+GATHER_MODE = "last"  # --gather: every | last | none
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 WORKLOADS = {
@@ -113,7 +116,9 @@ class Job:
         self.disp = self.pipe.estimate(self.left, self.right)
         if ev is not None:
             ev[2].record()
-        if world > 1 or (gather if gather is not None else FORCE_GATHER):
+        if gather is None:
+            gather = GATHER_MODE == "every"
+        if gather and (world > 1 or FORCE_GATHER):
             # The only collective of the job: every rank ends up with all disparity maps.
             import torch.distributed as dist
             if dist.get_backend() == "nccl":
@@ -154,7 +159,7 @@ class Job:
 def timed_run(job, steps, warmup, world):
     import torch.distributed as dist
     for _ in range(warmup):
-        job.step(world=world)
+        job.step(world=world, gather=GATHER_MODE != "none")
     job.finish_gather()
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
     if world > 1:
@@ -162,8 +167,12 @@ def timed_run(job, steps, warmup, world):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(steps):
-        job.step(events[k], world=world)
-    job.finish_gather()      # the last step's gather is part of the timed job
+        # (the sweeps of the tiled aggregation need every CU for their resident workgroups: a
+        # collective running beside every step would take CUs from them, so by default only the
+        # last step's maps are gathered)
+        job.step(events[k], world=world, gather=(GATHER_MODE == "every" or
+                                                  (GATHER_MODE == "last" and k == steps - 1)))
+    job.finish_gather()      # the gather is part of the timed job
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -340,12 +349,16 @@ def main():
     ap.add_argument("--no-config3", action="store_true", help="skip the Birchfield+SGM+DP extra line")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 per-call latencies")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--gather", default="last", choices=["every", "last", "none"],
+                    help="N > 1: all_gather of the disparity maps after every step / the last step / never")
     ap.add_argument("--rehearse-nccl", action="store_true",
                     help="rehearsal only: 1-rank RCCL group, gather code path exercised")
     ap.add_argument("--shared-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (with --backend gloo) on a 1-GPU box")
     args = ap.parse_args()
 
+    global GATHER_MODE
+    GATHER_MODE = args.gather
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -412,7 +425,8 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": w["config"], "H": w["H"], "W": w["W"], "D": w["D"],
                    "pairs_per_gpu_per_step": batch, "ssd_mode": "auto", "kernel_size": 7,
-                   "penalties": [0.1, 0.2], "sharding": "pairs over ranks, all_gather of disparity maps"},
+                   "penalties": [0.1, 0.2],
+                   "sharding": "pairs over ranks, no collective on the data path; all_gather of the disparity maps: " + args.gather},
         "stage_ms": {"ssd": round(stage_ms[0], 4), "sgm_wta_fused": round(stage_ms[1], 4),
                      "sgm_alone_unfused": round(job.unfused_sgm_ms(), 4)},
         "roofline": roofline(job, stage_ms[1], load_traffic(name, batch)),
