@@ -192,3 +192,35 @@ def test_config5_share_eight_1080p_pairs(device, oracle):
         S1 = sgm1(C1, Lb[b], S1)
         assert torch.equal(S1.view(torch.int32), Sb[b].view(torch.int32)), "sgm pair %d" % b
         assert torch.equal(wta(S1), fused_b[b]), "disparity pair %d" % b
+
+
+def test_teddy_large_batch_takes_the_tiled_form_and_matches_single_pairs(device, oracle):
+    """A 48-pair Teddy batch is what the bench's primary workload looks like to the library: the
+    aggregation takes the tiled form (row sweeps + two-lines-per-wave tiles, workgroups owning
+    tile rows).  Pair 0 must hash to the reference digests, and every pair must equal its own
+    single-pair run (paired form), sum volume and fused disparity map, bit for bit."""
+    import stereomatch
+    from stereomatch import _native
+    g = GOLDEN["teddy 375x450x128"]
+    H, W, D, B = g["H"], g["W"], g["D"], 48
+    assert _native.lib().stm_sgm_uses_tiles(H, W, D, B, 0) == 1, "the batch should take the tiled form"
+    assert _native.lib().stm_sgm_uses_tiles(H, W, D, 1, 0) == 0
+    pairs = [oracle.synthetic_pair(H, W, seed=s) for s in range(B)]
+    Lb = torch.from_numpy(np.stack([p[0] for p in pairs])).to(device)
+    Rb = torch.from_numpy(np.stack([p[1] for p in pairs])).to(device)
+    ssd = stereomatch.cost.SSD(D)
+    sgm = stereomatch.aggregation.Semiglobal()
+    wta = stereomatch.disparity_reduce.WinnerTakesAll()
+    Cb = ssd(Lb, Rb)
+    Sb = sgm(Cb, Lb)
+    assert sgm.status() == 0
+    _, fused_b = sgm.aggregate_and_reduce(Cb, Lb)
+    assert sgm.status() == 0
+    assert digest16(Cb[0]) == g["ssd"] and digest16(Sb[0]) == g["sgm"]
+    assert digest16(fused_b[0]) == g["ssd_sgm_wta"]
+    sgm1 = stereomatch.aggregation.Semiglobal()
+    S1 = None
+    for b in range(B):
+        S1 = sgm1(Cb[b], Lb[b], S1)
+        assert torch.equal(S1.view(torch.int32), Sb[b].view(torch.int32)), "sgm pair %d" % b
+        assert torch.equal(wta(S1), fused_b[b]), "fused pair %d" % b
