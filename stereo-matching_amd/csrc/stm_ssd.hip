@@ -591,6 +591,10 @@ extern "C" int stm_ssd_f32(const float *left, const float *right, float *cost, i
     long per_band = (long)T.tiles * T.chunks * batch;
     int band_h = 64;
     while (band_h > 16 && per_band * ((H + band_h - 1) / band_h) < 4096) band_h >>= 1;
+    // A single small pair does not even fill the SIMDs at 16 rows per band (Teddy: 384 waves on
+    // 1,024 SIMDs): then the kernel's time is one wave's, and shorter bands shorten it although
+    // each repeats the 13-row warm-up.
+    while (band_h > 4 && per_band * ((H + band_h - 1) / band_h) < 1024) band_h >>= 1;
     T.band_h = band_h;
     T.bands = (H + band_h - 1) / band_h;
     const long waves = per_band * T.bands;
