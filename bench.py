@@ -7,8 +7,10 @@ batch of synthetic stereo pairs that is already resident in HBM (through the
 BASELINE.json's: stereo pairs per second, whole job.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N ...          # N > 1 without a launcher: starts the N ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus 2 --backend gloo --shared-device   # rehearsal of the N-rank flow on a 1-GPU box
 
 Workloads (BASELINE.json ``configs``):
   teddy  = configs[1]: 375x450, SSD(128, k=7) + SGM(0.1, 0.2) + WTA      (primary, `value`)
@@ -89,7 +91,7 @@ class Job:
     on a [B, H, W] stack of pairs.  With this package's own ops the pipeline runs the
     aggregation and the winner-takes-all as one fused call (stm_sgm_wta_f32)."""
 
-    def __init__(self, name, batch, rank, device):
+    def __init__(self, name, batch, rank, device, form="auto"):
         import stereomatch
         w = WORKLOADS[name]
         self.name, self.w, self.batch, self.device = name, w, batch, device
@@ -98,7 +100,7 @@ class Job:
         self.left = torch.from_numpy(np.stack([p[0] for p in pairs])).to(device)
         self.right = torch.from_numpy(np.stack([p[1] for p in pairs])).to(device)
         self.cost_op = _TimedCost(stereomatch.cost.SSD(D, kernel_size=7))
-        self.sgm = stereomatch.aggregation.Semiglobal(0.1, 0.2)
+        self.sgm = stereomatch.aggregation.Semiglobal(0.1, 0.2, form=form)
         self.pipe = stereomatch.Pipeline(self.cost_op, stereomatch.disparity_reduce.WinnerTakesAll(),
                                          self.sgm)
         self.disp = None
@@ -158,9 +160,11 @@ class Job:
 
 def timed_run(job, steps, warmup, world):
     import torch.distributed as dist
-    for _ in range(warmup):
-        job.step(world=world, gather=GATHER_MODE != "none")
-    job.finish_gather()
+    for k in range(warmup):
+        # The last warm-up step rehearses the gather (RCCL sets its communicator up on first
+        # use) and finishes it before anything else is launched; the others do not gather.
+        job.step(world=world, gather=(GATHER_MODE != "none" and k == warmup - 1))
+        job.finish_gather()
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
     if world > 1:
         dist.barrier()
@@ -335,6 +339,23 @@ def config3_line(device, steps, batch=16):
             "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4)}
 
 
+def self_launch(n):
+    """--gpus N > 1 without a launcher's environment: start the N ranks as children (the same
+    command line under torch.distributed.run) and relay their output.  Called before anything
+    in this process has touched the GPU; this process only waits and exits with the children's
+    code -- it is never replaced by another program."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL between processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -355,7 +376,13 @@ def main():
                     help="rehearsal only: 1-rank RCCL group, gather code path exercised")
     ap.add_argument("--shared-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (with --backend gloo) on a 1-GPU box")
+    ap.add_argument("--form", default=None, choices=["auto", "paired", "tiled"],
+                    help="form of the aggregation (default: auto; paired with --shared-device, "
+                         "since ranks sharing one GPU must not run tiled aggregations side by side)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+    form = args.form or ("paired" if args.shared_device else "auto")
 
     global GATHER_MODE
     GATHER_MODE = args.gather
@@ -380,7 +407,7 @@ def main():
             dist.init_process_group(backend="nccl", device_id=device)
         else:
             dist.init_process_group(backend=args.backend)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    assert world == args.gpus, "WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus)
 
     from stereomatch import _native
     _native.lib()  # no HIP library -> fail loudly, there is no fallback
@@ -409,12 +436,34 @@ def main():
                 import torch.distributed as dist
                 dist.destroy_process_group()
             sys.exit(1)
+        check_status(job, label + " (gate)")
+
+    def check_status(job, label):
+        """The tiled aggregation's status word, all ranks: a set bit (its row sweeps waited for
+        workgroups that were not resident) means invalid results -- no metric is printed."""
+        st = int(job.sgm.status())
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([st], dtype=torch.int32,
+                             device=device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            st = int(t.item())
+        if st:
+            if rank == 0:
+                print("aggregation status word %d after %s: results invalid, no metric" % (st, label),
+                      file=sys.stderr, flush=True)
+            if world > 1:
+                import torch.distributed as dist
+                dist.destroy_process_group()
+            sys.exit(2)
+        return st
 
     name = args.workload
     batch = args.batch or WORKLOADS[name]["batch"]
-    job = Job(name, batch, rank, device)
+    job = Job(name, batch, rank, device, form)
     gate(job, name)
     elapsed, stage_ms = timed_run(job, args.steps, args.warmup, world)
+    sgm_status = check_status(job, name + " (timed loop)")
     pairs = batch * world * args.steps
     value = pairs / elapsed
     w = WORKLOADS[name]
@@ -431,6 +480,7 @@ def main():
                      "sgm_alone_unfused": round(job.unfused_sgm_ms(), 4)},
         "roofline": roofline(job, stage_ms[1], load_traffic(name, batch)),
         "csrc_sha16": csrc_sha16(),
+        "sgm_status": sgm_status,  # status word of the tiled aggregation after the timed loop (0 = ok)
     }
     del job
     torch.cuda.empty_cache()
@@ -440,9 +490,10 @@ def main():
         # is BASELINE config 5 (64 pairs sharded over 8 GPUs, disparity maps gathered).
         w2 = WORKLOADS[args.also]
         b2 = args.also_batch or w2["batch"]
-        job2 = Job(args.also, b2, rank, device)
+        job2 = Job(args.also, b2, rank, device, form)
         gate(job2, args.also)
         e2, s2 = timed_run(job2, args.also_steps, 1, world)
+        check_status(job2, args.also + " (timed loop)")
         d7 = float((job2.disp == 7).float().mean())
         out["also"] = {
             "workload": w2["config"] + (" x %d pairs sharded over %d GPUs" % (b2 * world, world)

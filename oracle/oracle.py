@@ -102,13 +102,19 @@ def birchfield(left, right, max_disparity, out=None, padded=False):
     return out
 
 
-def sgm(cost_volume, left, penalty1=0.1, penalty2=0.2, full_min=False, true_paths=False):
+def sgm(cost_volume, left, penalty1=0.1, penalty2=0.2, full_min=False, true_paths=False, out=None):
     """``full_min`` / ``true_paths`` select the corrected-algorithm variants (extensions of
-    the HIP library); the defaults are the reference's behaviour."""
+    the HIP library); the defaults are the reference's behaviour.  The reference accumulates
+    into its output tensor (src/semiglobal.cpp:150-156; the wrapper zero-fills it first,
+    aggregation.py:51): ``out`` = the contents to accumulate on top of (default zeros)."""
     cost_volume, cp = _f32(cost_volume)
     left, ip = _f32(left)
     H, W, D = cost_volume.shape
-    out = np.zeros((H, W, D), dtype=np.float32)
+    if out is None:
+        out = np.zeros((H, W, D), dtype=np.float32)
+    else:
+        out = np.array(out, dtype=np.float32, order="C", copy=True)
+        assert out.shape == (H, W, D)
     flags = (1 if full_min else 0) | (2 if true_paths else 0)
     _check(lib().orc_sgm_ex_f32(cp, ip, out.ctypes.data_as(_f32p), H, W, D,
                                 penalty1, penalty2, flags), "sgm")

@@ -750,8 +750,15 @@ static SgmPlan sgm_plan(int H, int W, int D, int batch, bool paired, bool true_p
 #if !STM_SGM_EXACT
 extern "C" size_t stm_sgm_workspace_bytes(int H, int W, int D, int batch, int flags) {
   if (H <= 0 || W <= 0 || D <= 0 || batch <= 0 || D > STM_MAX_DISPARITY) return 0;
-  if (stm::sgm_tiled_selected(H, W, D, batch, flags))
-    return stm::sgm_tiled_workspace_bytes(H, W, D, batch, flags);
+  if (stm::sgm_tiled_selected(H, W, D, batch, flags)) {
+    // Chosen by the library, not forced: a call whose pointers turn out not to be 16-byte
+    // aligned takes the paired form behind the same header, so the workspace fits either.
+    const size_t tiled = stm::sgm_tiled_workspace_bytes(H, W, D, batch, flags);
+    if (flags & STM_SGM_TILED) return tiled;
+    const size_t paired = stm::kSgmWorkspaceHeader +
+        sgm_plan(H, W, D, batch, true, (flags & STM_SGM_TRUE_PATHS) != 0).total_floats * sizeof(float);
+    return tiled > paired ? tiled : paired;
+  }
   return sgm_plan(H, W, D, batch, !(flags & STM_SGM_SINGLE_PASSES), (flags & STM_SGM_TRUE_PATHS) != 0).total_floats * sizeof(float);
 }
 
@@ -832,9 +839,21 @@ static int sgm_run(const float *cost, const float *left, float *out, int32_t *di
   STM_REQUIRE(final_mode == 0 || (paired && disp), STM_EINVAL,
               "stm_sgm_wta_f32: needs a disparity pointer and the paired form");
 #if !STM_SGM_EXACT
-  if (sgm_tiled_selected(H, W, D, batch, flags))
-    return sgm_run_tiled(cost, left, out, disp, H, W, D, penalty1, penalty2, flags, workspace,
-                         workspace_bytes, batch, as_stream(stream), final_mode);
+  if (sgm_tiled_selected(H, W, D, batch, flags)) {
+    if ((flags & STM_SGM_TILED) || sgm_tiled_aligned(cost, out, workspace, final_mode))
+      return sgm_run_tiled(cost, left, out, disp, H, W, D, penalty1, penalty2, flags, workspace,
+                           workspace_bytes, batch, as_stream(stream), final_mode);
+    // The library's own choice, but this call's pointers are not 16-byte aligned (e.g. an offset
+    // view handed in as the output): the paired form takes it, behind the workspace header the
+    // caller expects for this shape (its status word reads "ok": the paired form never waits).
+    STM_REQUIRE(workspace && workspace_bytes >= kSgmWorkspaceHeader, STM_EWORKSPACE,
+                "stm_sgm_f32: needs a workspace of %zu bytes (stm_sgm_workspace_bytes)",
+                stm_sgm_workspace_bytes(H, W, D, batch, flags));
+    if (hipMemsetAsync(workspace, 0, sizeof(unsigned), as_stream(stream)) != hipSuccess)
+      return fail(STM_EHIP, "stm_sgm_f32: hipMemsetAsync failed");
+    workspace = static_cast<char *>(workspace) + kSgmWorkspaceHeader;
+    workspace_bytes -= kSgmWorkspaceHeader;
+  }
 #endif
   const bool true_paths = (flags & STM_SGM_TRUE_PATHS) != 0;
   const int dlim = (flags & STM_SGM_FULL_MIN) ? D : D - 1;

@@ -11,6 +11,14 @@ namespace stm {
 // stm_sgm_workspace_bytes() and stm_sgm_f32() always agree.
 bool sgm_tiled_selected(int H, int W, int D, int batch, int flags);
 
+// The tiled form moves whole 16-byte lanes: cost, out and workspace must be 16-byte aligned
+// (a call that is not, and does not force STM_SGM_TILED, takes the paired form instead).
+bool sgm_tiled_aligned(const void *cost, const void *out, const void *workspace, int final_mode);
+
+// Bytes at the head of the workspace of every call for which sgm_tiled_selected() holds: the
+// status word (whichever form then runs), padded so that what follows stays 16-byte aligned.
+constexpr size_t kSgmWorkspaceHeader = 256;
+
 // Workspace the tiled form needs for this call (0 when it is not selected).
 size_t sgm_tiled_workspace_bytes(int H, int W, int D, int batch, int flags);
 

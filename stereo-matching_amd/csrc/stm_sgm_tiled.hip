@@ -102,6 +102,10 @@ __device__ __forceinline__ u64 *mbox_ptr(float *ws, const TiledGeom &G, int swee
 // two mailboxes per strip edge and row turned into a tenth of the stage's write traffic.
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 constexpr int kAuxSc1 = 16;  // cache-policy bits of the raw buffer builtins: sc1 (write-through / L2-served)
+// The same for the mailbox traffic itself: bit 31 marks the access volatile for the compiler (it
+// is not an instruction bit), so a polling load is re-issued on every trip of a wait loop and a
+// publishing store is never merged or dropped.
+constexpr int kAuxMbox = (int)(0x80000000u | (unsigned)kAuxSc1);
 
 template <int VPL>
 __device__ __forceinline__ void mbox_publish(u64 *box, int D, int d0, unsigned row, const Row<VPL> &r) {
@@ -114,7 +118,7 @@ __device__ __forceinline__ void mbox_publish(u64 *box, int D, int d0, unsigned r
       v4u_t q;
       q.x = __builtin_bit_cast(unsigned, r.v[j]); q.y = tag;
       q.z = __builtin_bit_cast(unsigned, r.v[j + 1]); q.w = tag;
-      __builtin_amdgcn_raw_buffer_store_b128(q, rs, (d0 + j) * 8, 0, kAuxSc1);
+      __builtin_amdgcn_raw_buffer_store_b128(q, rs, (d0 + j) * 8, 0, kAuxMbox);
     }
   } else {
 #pragma unroll
@@ -137,7 +141,7 @@ __device__ __forceinline__ void mbox_peek(const u64 *box, int D, int d0, unsigne
     const BufRsrc rs = make_rsrc(slot - d0, (unsigned)(D * sizeof(u64)));
 #pragma unroll
     for (int j = 0; j < VPL; j += 2) {
-      const v4u_t g = __builtin_amdgcn_raw_buffer_load_b128(rs, (d0 + j) * 8, 0, kAuxSc1);
+      const v4u_t g = __builtin_amdgcn_raw_buffer_load_b128(rs, (d0 + j) * 8, 0, kAuxMbox);
       q.val[j] = g.x; q.tag[j] = g.y;
       q.val[j + 1] = g.z; q.tag[j + 1] = g.w;
     }
@@ -179,6 +183,7 @@ __device__ __forceinline__ void mbox_wait(const u64 *box, int D, int d0, unsigne
   const u64 t0 = __builtin_amdgcn_s_memrealtime();
   for (;;) {
     __builtin_amdgcn_s_sleep(2);
+    asm volatile("" ::: "memory");  // (and nothing the loop reads is carried over from the last trip)
     if (mbox_try<VPL>(box, D, d0, row, r)) return;
     if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
       dead = true;
@@ -727,11 +732,7 @@ template <int VPL>
 __global__ __launch_bounds__(256) void sgm_hwalk_kernel(const float *__restrict__ cost_all,
                                                         const float *__restrict__ image_all,
                                                         float *__restrict__ ws, const HwalkArgs P) {
-#ifdef STM_HWALK_RECOMPUTE_PROBE
-  constexpr int PF = 16;  // = the register ring of window columns (14 used)
-#else
   constexpr int PF = 8;
-#endif
   constexpr int D = 64 * VPL;
   const TiledGeom &G = P.G;
   const int lane = threadIdx.x & 63;
@@ -762,15 +763,6 @@ __global__ __launch_bounds__(256) void sgm_hwalk_kernel(const float *__restrict_
 #pragma unroll
   for (int u = 0; u < PF; ++u) cbuf[u] = load_row<VPL, true>(cost, (size_t)col_of(imin(u, last)), D, d0);
   Row<VPL> prev = cbuf[0];
-#ifdef STM_HWALK_RECOMPUTE_PROBE
-  __shared__ float probe_lds_all[4][14 * (D + 64) + 64];
-  float *probe_lds = probe_lds_all[threadIdx.x >> 6];
-  for (int e = lane; e < 14 * (D + 64) + 64; e += 64) probe_lds[e] = (float)((e * 7 + y) & 255);
-  float probe_left = (float)((lane * 13 + y) & 255);
-  Row<VPL> probe_acc = cbuf[0], probe_ring[PF];
-#pragma unroll
-  for (int u = 0; u < PF; ++u) probe_ring[u] = cbuf[u];
-#endif
   const int keep = left ? 0 : kT - 1;
   const int k = left ? 3 : 0;
   for (int base = 0; base < W; base += PF) {
@@ -782,41 +774,8 @@ __global__ __launch_bounds__(256) void sgm_hwalk_kernel(const float *__restrict_
     for (int u = 0; u < PF; ++u) {
       const int i = base + u;
       if (i < W) {
-#ifdef STM_HWALK_RECOMPUTE_PROBE
-        // Timing probe (tools/build_probe.sh recompute; never in the product): what the walk
-        // would cost if it rebuilt the SSD cost of its pixel instead of loading it.  The
-        // arithmetic of the integer-exact sliding form along a row: one new window column per
-        // step = 14 rows x (left sample by v_readlane, right samples of the lane's
-        // disparities by one 16-byte LDS read, subtract, multiply, add), plus the leaving
-        // column from a 16-deep register ring.  The staged data is synthetic (no image rows
-        // are loaded or staged, which a real kernel would have to do on top), so the result is
-        // meaningless and only the kernel's time is looked at: a lower bound.
-        Row<VPL> c;
-        {
-          Row<VPL> col;
-#pragma unroll
-          for (int j = 0; j < VPL; ++j) col.v[j] = 0.0f;
-#pragma unroll
-          for (int kr = 0; kr < 14; ++kr) {
-            const float lv = read_lane(probe_left, (kr + u) & 63);
-            const Row<VPL> rv = load_row<VPL, true>(probe_lds + kr * (D + 64) + 4 * ((i + kr) & 15), 0, D, d0);
-#pragma unroll
-            for (int j = 0; j < VPL; ++j) {
-              const float t = lv - rv.v[j];
-              col.v[j] = col.v[j] + t * t;
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < VPL; ++j) {
-            probe_acc.v[j] = (probe_acc.v[j] + col.v[j]) - probe_ring[u].v[j];
-            probe_ring[u].v[j] = col.v[j];
-            c.v[j] = probe_acc.v[j];
-          }
-        }
-#else
         const Row<VPL> c = cbuf[u];
         cbuf[u] = load_row<VPL, true, true>(cost, (size_t)col_of(imin(i + PF, last)), D, d0);
-#endif
         if (i > 0) prev = sgm_step<VPL, true>(prev, c, read_lane(pen, i & (kWave - 1)), X);
         const int x = col_of(i);
         if ((x & (kT - 1)) == keep) store_row<VPL, true, true>(colb_ptr(ws, G, b, k, x >> 3, y), 0, D, d0, prev);
@@ -843,6 +802,7 @@ struct TileArgs {
   float p1, p2;
   int dlim;
   int true_paths;
+  int accumulate;  // STM_SGM_ACCUMULATE: the sum starts from the caller's contents of `out`, not from 0
 #ifdef STM_TILE_STAMPS
   unsigned long long *stamps;  // diagnostic build only: [tile][wave][8] s_memtime stamps
 #endif
@@ -1109,8 +1069,12 @@ __device__ __forceinline__ void tile_add(const PhaseGeom &g, const Slots<PHASE> 
       const int pix = sl.pix[s];
       Row<VPL> acc;
       if (PHASE == 0) {
+        if (P.accumulate) {
+          acc = load_row<VPL, true>(out, (size_t)(y0 + (pix >> 3)) * P.G.W + (x0 + (pix & (kT - 1))), D, d0);
+        } else {
 #pragma unroll
-        for (int j = 0; j < VPL; ++j) acc.v[j] = 0.0f;
+          for (int j = 0; j < VPL; ++j) acc.v[j] = 0.0f;
+        }
       } else {
         acc = lds_row<VPL>(St, pix, d0);
       }
@@ -1279,7 +1243,7 @@ __device__ __forceinline__ void tile_pair(const PhaseGeom &g, const Entries<VPL,
   // (the reference skips the inverse diagonals of 17-44 % of a wide image's pixels, Q6: those
   // segments' I chains are not even computed); what is left for the generic forms are the
   // tiles on the image border and on the re-walked corner diagonals.
-  bool fast = full && E.start == 0;
+  bool fast = full && E.start == 0 && !(PHASE == 0 && P.accumulate);  // (accumulating: pair 0 starts from `out`, tile_add)
   bool inv_a = true, inv_b = true;
   if (PHASE >= 2 && fast) {
     const Counts ca = seg_counts<PHASE>(g.a, x0, y0, P.G, P.true_paths);
@@ -1288,22 +1252,6 @@ __device__ __forceinline__ void tile_pair(const PhaseGeom &g, const Entries<VPL,
     inv_a = ca.inv != 0;
     inv_b = cb.inv != 0;
   }
-#ifdef STM_TILE_ABLATE
-  // Timing ablations (tools/build_probe.sh ablate; results are wrong, only times are read):
-  // 1 = no sum updates, 2 = no chains, 4 = no final output / winner-takes-all.
-  if (fast) {
-    if (!(STM_TILE_ABLATE & 2)) tile_chains_fast<VPL, PHASE>(sl, E, inv_a, inv_b, Ct, Ip, P.p1, P.p2, X, lane, LF, LI);
-    else {
-#pragma unroll
-      for (int q = 0; q < kT; ++q) { LF[q] = E.e[0]; LI[q] = E.e[1]; }
-    }
-    between();
-    if (!(STM_TILE_ABLATE & 1) && !((STM_TILE_ABLATE & 4) && PHASE == 3))
-      tile_add_fast<VPL, PHASE, FINAL>(sl, LF, LI, inv_a, inv_b, St, P.G.W, x0, y0, out, disp, lane);
-    else if (lane == 0 && LF[0].v[0] + LI[7].v[0] == 12345.678f) St[0] = 1.0f;  // keeps the chains alive
-    return;
-  }
-#endif
   if (fast) {
     tile_chains_fast<VPL, PHASE>(sl, E, inv_a, inv_b, Ct, Ip, P.p1, P.p2, X, lane, LF, LI);
     between();
@@ -1679,7 +1627,7 @@ __device__ __forceinline__ void h2_lds_store(float *tile, int byte_addr, const R
 // behind which the previous pair's update is complete), the update S = (S + F) + I.
 template <int PHASE, int NA, int FINAL, typename Between>
 __device__ __forceinline__ void h2_pair(const H2Pair &K, const Row<4> (&E)[4], int cls, int w, int half, const TiledGeom &G,
-                                        int true_paths, const float *Ct,
+                                        int true_paths, int accumulate, const float *Ct,
                                         float *St, float pen, StepCtxH2 &X, int lane,
                                         int hl16, int W, int x0, int y0, float *__restrict__ out,
                                         int32_t *__restrict__ disp, Row<4> &exit_f, Between between) {
@@ -1719,8 +1667,13 @@ __device__ __forceinline__ void h2_pair(const H2Pair &K, const Row<4> (&E)[4], i
   auto update = [&](auto s_, Row<4> &acc) {
     constexpr int s = decltype(s_)::value;
     if (PHASE == 0) {
+      if (accumulate) {  // STM_SGM_ACCUMULATE: the sum starts from the caller's contents of `out`
+        const int p = s < NA ? K.pix0 + s * pstep : K.pix1 + (s - NA) * pstep;
+        acc = load_row<4, true>(out, (size_t)((y0 + (p >> 3)) * W + (x0 + (p & (kT - 1)))), 128, hl16 >> 2);
+      } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc.v[j] = 0.0f;
+        for (int j = 0; j < 4; ++j) acc.v[j] = 0.0f;
+      }
     }
     f32x2 lo = f32x2{acc.v[0], acc.v[1]}, hi = f32x2{acc.v[2], acc.v[3]};
     const f32x2 ilo = f32x2{LI[s].v[0], LI[s].v[1]}, ihi = f32x2{LI[s].v[2], LI[s].v[3]};
@@ -1887,7 +1840,7 @@ __device__ __forceinline__ void h2_pair_w(int w, int half, const H2Pair &K, cons
                                           float *__restrict__ out, int32_t *__restrict__ disp, Row<4> &exit_f,
                                           Between between) {
 #define STM_H2_PAIR(NA)                                                                              \
-  h2_pair<PHASE, NA, FINAL>(K, E, cls, w, half, P.G, P.true_paths, Ct, St, pen, X, lane, hl16, P.G.W, x0, y0, \
+  h2_pair<PHASE, NA, FINAL>(K, E, cls, w, half, P.G, P.true_paths, P.accumulate, Ct, St, pen, X, lane, hl16, P.G.W, x0, y0, \
                             out, disp, exit_f, between)
   if constexpr (PHASE < 2) {
     STM_H2_PAIR(kT);
@@ -2172,9 +2125,63 @@ bool make_plan(int H, int W, int D, int batch, TiledPlan &plan) {
   return true;
 }
 
+// Launches one row sweep.  Its workgroups wait for each other, so all of them must be resident
+// together: the launch is a COOPERATIVE one (hipLaunchCooperativeKernel), which the runtime
+// refuses when the grid exceeds what the device can hold at once for this kernel (registers,
+// LDS, a CU mask) instead of letting the waits run into their timeouts; make_plan() has sized
+// the grid to the CU count and sweep_fits() has checked the kernel's occupancy before.  What a
+// cooperative launch cannot see is a CU that is busy with somebody else's long-running
+// workgroups: the bounded waits and the status word remain the backstop for that.  While the
+// stream is being captured into a graph the plain launch is used (a cooperative launch is not
+// capturable on every runtime); replaying such a graph is under the caller's "nothing else
+// holds the device's CUs" contract.
+template <typename Kernel>
+int launch_sweep(Kernel kernel, dim3 grid, dim3 block, hipStream_t s, const float *cost, const float *left,
+                 float *ws, const SweepArgs &A) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+  static const bool plain = getenv("STM_SWEEP_PLAIN_LAUNCH") != nullptr;  // development: A/B the two launch paths
+  if (capturing || plain) {
+    hipLaunchKernelGGL(kernel, grid, block, 0, s, cost, left, ws, A);
+    return check_launch("stm_sgm_f32 (tiled: row sweep)");
+  }
+  void *args[] = {(void *)&cost, (void *)&left, (void *)&ws, (void *)&A};
+  const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(kernel), grid, block, args, 0, s);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(STM_EHIP,
+                "stm_sgm_f32 (tiled: row sweep): the device cannot hold the sweep's %u x %u workgroups at once "
+                "(%s); use STM_SGM_PAIRED for this call", grid.x, grid.y, hipGetErrorString(e));
+  }
+  return STM_OK;
+}
+
+// Whether one sweep workgroup per CU fits (registers, LDS) -- per device and D, asked once.
+template <int VPL>
+bool sweep_fits_vpl() {
+  constexpr int CW = 8 / VPL;
+  int n0 = 0, n1 = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n0, sgm_sweep_kernel<VPL, CW, false>, kSweepWaves * 64, 0) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, sgm_sweep_kernel<VPL, CW, true>, kSweepWaves * 64, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return n0 >= 1 && n1 >= 1;
+}
+bool sweep_fits(int D) {
+  static signed char cache[16][3];  // [device][VPL index]: 0 unknown, 1 fits, -1 does not
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  const int k = D == 64 ? 0 : (D == 128 ? 1 : 2);
+  if (dev >= 0 && dev < 16 && cache[dev][k] != 0) return cache[dev][k] > 0;
+  const bool ok = D == 64 ? sweep_fits_vpl<1>() : (D == 128 ? sweep_fits_vpl<2>() : sweep_fits_vpl<4>());
+  if (dev >= 0 && dev < 16) cache[dev][k] = ok ? 1 : -1;
+  return ok;
+}
+
 template <int VPL>
 int run_tiled(const float *cost, const float *left, float *out, int32_t *disp, const TiledPlan &plan,
-              float p1, float p2, int dlim, int true_paths, float *ws, int batch, hipStream_t s,
+              float p1, float p2, int dlim, int true_paths, int accumulate, float *ws, int batch, hipStream_t s,
               int final_mode) {
   const TiledGeom &G = plan.G;
   if (hipMemsetAsync(ws, 0, plan.zero_bytes, s) != hipSuccess)
@@ -2205,16 +2212,15 @@ int run_tiled(const float *cost, const float *left, float *out, int32_t *disp, c
       const int n = batch - b0 < plan.group ? batch - b0 : plan.group;
       const dim3 grid(G.strips, n), block(kSweepWaves * 64);
       constexpr int CW = 8 / VPL;  // = sweep_cw(VPL)
-      if (up) hipLaunchKernelGGL((sgm_sweep_kernel<VPL, CW, true>), grid, block, 0, s, cost, left, ws, A);
-      else hipLaunchKernelGGL((sgm_sweep_kernel<VPL, CW, false>), grid, block, 0, s, cost, left, ws, A);
-      int rc = check_launch("stm_sgm_f32 (tiled: row sweep)");
+      const int rc = up ? launch_sweep(sgm_sweep_kernel<VPL, CW, true>, grid, block, s, cost, left, ws, A)
+                        : launch_sweep(sgm_sweep_kernel<VPL, CW, false>, grid, block, s, cost, left, ws, A);
       if (rc != STM_OK) return rc;
     }
   }
   if (skip & 4) return STM_OK;
   {
     TileArgs A;
-    A.G = G; A.p1 = p1; A.p2 = p2; A.dlim = dlim; A.true_paths = true_paths;
+    A.G = G; A.p1 = p1; A.p2 = p2; A.dlim = dlim; A.true_paths = true_paths; A.accumulate = accumulate;
 #ifdef STM_TILE_STAMPS
     A.stamps = g_tile_stamps;
 #endif
@@ -2256,8 +2262,7 @@ int run_tiled(const float *cost, const float *left, float *out, int32_t *disp, c
 }
 
 bool shape_ok(int H, int W, int D, int batch, int flags) {
-  if (flags & (STM_SGM_ACCUMULATE | STM_SGM_SINGLE_PASSES | STM_SGM_EXACT_NONFINITE | STM_SGM_PAIRED))
-    return false;
+  if (flags & (STM_SGM_SINGLE_PASSES | STM_SGM_EXACT_NONFINITE | STM_SGM_PAIRED)) return false;
   if (D != 64 && D != 128 && D != 256) return false;
   if (H < 1 || W < 1 || batch < 1 || batch > 65535) return false;
   if ((long long)batch * ((H + kT - 1) / kT) * ((W + kT - 1) / kT) > 0x3fffffffll) return false;
@@ -2270,6 +2275,7 @@ bool sgm_tiled_selected(int H, int W, int D, int batch, int flags) {
   if (!shape_ok(H, W, D, batch, flags)) return false;
   TiledPlan plan;
   if (!make_plan(H, W, D, batch, plan)) return false;
+  if (!sweep_fits(D)) return false;
   if (flags & STM_SGM_TILED) return true;
   // Measured on MI355X (tools/sgm_forms.py): the tiled form wins where the volume traffic it
   // saves outweighs its fixed costs per image row and per tile, i.e. for wide disparity ranges
@@ -2282,6 +2288,11 @@ bool sgm_tiled_selected(int H, int W, int D, int batch, int flags) {
   const int strip_cols = kSweepWaves * sweep_cw(D / 64);
   const long long need = (long long)cus * strip_cols * (D == 256 ? 9 : 15);  // tenths
   return D >= 128 && (long long)batch * W * 2 * 10 >= need && H >= 64;
+}
+
+bool sgm_tiled_aligned(const void *cost, const void *out, const void *workspace, int final_mode) {
+  return (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && (reinterpret_cast<uintptr_t>(cost) & 15) == 0 &&
+         (reinterpret_cast<uintptr_t>(out) & 15) == 0;  // (`out` is read by STM_SGM_ACCUMULATE even when it is not written)
 }
 
 size_t sgm_tiled_workspace_bytes(int H, int W, int D, int batch, int flags) {
@@ -2300,17 +2311,16 @@ int sgm_run_tiled(const float *cost, const float *left, float *out, int32_t *dis
   const size_t need = plan.total_floats * sizeof(float);
   STM_REQUIRE(workspace && workspace_bytes >= need, STM_EWORKSPACE,
               "stm_sgm_f32: needs a workspace of %zu bytes (stm_sgm_workspace_bytes)", need);
-  STM_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0 &&
-                  (reinterpret_cast<uintptr_t>(cost) & 15) == 0 &&
-                  (final_mode == 2 || (reinterpret_cast<uintptr_t>(out) & 15) == 0),
-              STM_EINVAL, "stm_sgm_f32: the tiled form needs 16-byte aligned volumes and workspace");
+  STM_REQUIRE(sgm_tiled_aligned(cost, out, workspace, final_mode), STM_EINVAL,
+              "stm_sgm_f32: the tiled form needs 16-byte aligned volumes and workspace");
   const int dlim = (flags & STM_SGM_FULL_MIN) ? D : D - 1;
   const int true_paths = (flags & STM_SGM_TRUE_PATHS) ? 1 : 0;
+  const int acc = (flags & STM_SGM_ACCUMULATE) ? 1 : 0;
   float *ws = static_cast<float *>(workspace);
   switch (D / 64) {
-    case 1: return run_tiled<1>(cost, left, out, disp, plan, penalty1, penalty2, dlim, true_paths, ws, batch, stream, final_mode);
-    case 2: return run_tiled<2>(cost, left, out, disp, plan, penalty1, penalty2, dlim, true_paths, ws, batch, stream, final_mode);
-    default: return run_tiled<4>(cost, left, out, disp, plan, penalty1, penalty2, dlim, true_paths, ws, batch, stream, final_mode);
+    case 1: return run_tiled<1>(cost, left, out, disp, plan, penalty1, penalty2, dlim, true_paths, acc, ws, batch, stream, final_mode);
+    case 2: return run_tiled<2>(cost, left, out, disp, plan, penalty1, penalty2, dlim, true_paths, acc, ws, batch, stream, final_mode);
+    default: return run_tiled<4>(cost, left, out, disp, plan, penalty1, penalty2, dlim, true_paths, acc, ws, batch, stream, final_mode);
   }
 }
 

@@ -53,6 +53,9 @@ class Semiglobal:
         self.single_passes = single_passes
         self._workspace = None
         self._last_tiled = False
+        # Status word of the last tiled call, on its way to the host (see status()).
+        self._status_host = None
+        self._status_event = None
 
     def __call__(self, cost_volume: torch.Tensor, left_image: torch.Tensor,
                  sga_volume: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -101,13 +104,17 @@ class Semiglobal:
                                           reuse=disparity_img)
             if keep_sum:
                 flags |= _native.STM_SGM_KEEP_SUM
-        ws_bytes = lib.stm_sgm_workspace_bytes(height, width, max_disparity, batch, flags)
-        self._last_tiled = bool(lib.stm_sgm_uses_tiles(height, width, max_disparity, batch, flags))
-        if ws_bytes and (self._workspace is None or self._workspace.device != device
-                         or self._workspace.numel() < ws_bytes):
-            self._workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
-        ws_ptr = self._workspace.data_ptr() if (ws_bytes and self._workspace is not None) else None
+        # A previous call whose row sweeps ran into their bounded waits produced an invalid
+        # result: say so as soon as its status word has arrived (never blocks).
+        self._raise_if_failed(block=False)
         with torch.cuda.device(device):
+            # (form selection and workspace layout depend on the current device's CU count)
+            ws_bytes = lib.stm_sgm_workspace_bytes(height, width, max_disparity, batch, flags)
+            self._last_tiled = bool(lib.stm_sgm_uses_tiles(height, width, max_disparity, batch, flags))
+            if ws_bytes and (self._workspace is None or self._workspace.device != device
+                             or self._workspace.numel() < ws_bytes):
+                self._workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+            ws_ptr = self._workspace.data_ptr() if (ws_bytes and self._workspace is not None) else None
             if fused:
                 _native.check(lib.stm_sgm_wta_f32(
                     cost.data_ptr(), image.data_ptr(), sga_volume.data_ptr(),
@@ -119,13 +126,57 @@ class Semiglobal:
                     cost.data_ptr(), image.data_ptr(), sga_volume.data_ptr(), height, width,
                     max_disparity, float(self.penalty1), float(self.penalty2), flags, ws_ptr,
                     ws_bytes, batch, _native.stream_ptr(device)))
+            self._post_status(device)
         return sga_volume, disparity_img
 
-    def status(self) -> int:
-        """Status word of the last call's workspace (synchronises the device): 0 = ok; bit 0 =
-        a bounded wait inside the tiled form's row sweeps expired and that call's results are
-        invalid (include/stereomatch_hip.h, "Workspace header")."""
+    # ---- status word of the tiled form (include/stereomatch_hip.h, "Workspace header") -------
+    # The row sweeps of the tiled form exchange values between workgroups that must all be
+    # resident; their waits are bounded, and a wait that expires (the device's CUs were held by
+    # something else for seconds) sets bit 0 of the workspace's first word: that call's results
+    # are invalid.  The entry points never synchronise, so the word is brought to the host
+    # asynchronously behind every tiled call and looked at (a) without blocking at the start of
+    # the next call, (b) by status() / check(), which wait for it -- the callers' existing
+    # synchronisation points (Pipeline.status(), distributed.estimate_sharded, bench.py).
+    def _post_status(self, device) -> None:
+        self._status_event = None
         if not self._last_tiled or self._workspace is None or self._workspace.numel() < 4:
-            return 0  # the paired form has no bounded waits (and no status word)
+            return
+        if torch.cuda.is_current_stream_capturing():
+            return  # (a captured call is checked through status(), which reads the device word)
+        if self._status_host is None:
+            self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._status_host.copy_(self._workspace[:4].view(torch.int32), non_blocking=True)
+        self._status_event = torch.cuda.Event()
+        self._status_event.record(torch.cuda.current_stream(device))
+
+    def _raise_if_failed(self, block: bool) -> None:
+        ev = self._status_event
+        if ev is None or not (block or ev.query()):
+            return
+        ev.synchronize()
+        self._status_event = None
+        word = int(self._status_host.item())
+        if word:
+            raise RuntimeError(
+                "Semiglobal: the previous tiled aggregation's results are invalid (status word %d: "
+                "its row sweeps waited ~2 s for workgroups that were not resident -- the device's "
+                "CUs were held by other work); re-run that call with Semiglobal(form='paired')" % word)
+
+    def status(self) -> int:
+        """Status word of the last call (waits for that call): 0 = ok; bit 0 = a bounded wait
+        inside the tiled form's row sweeps expired and that call's results are invalid.  The
+        paired form has no waits and always reports 0."""
+        if not self._last_tiled or self._workspace is None or self._workspace.numel() < 4:
+            return 0
+        if self._status_event is not None:
+            self._status_event.synchronize()
+            return int(self._status_host.item())
         torch.cuda.synchronize(self._workspace.device)
         return int(self._workspace[:4].view(torch.int32).item())
+
+    def check(self) -> None:
+        """Waits for the last call and raises RuntimeError if its status word is set."""
+        if self.status():
+            self._raise_if_failed(block=True)
+            raise RuntimeError("Semiglobal: the last tiled aggregation's results are invalid "
+                               "(status word set); re-run with Semiglobal(form='paired')")

@@ -75,6 +75,20 @@ def estimate_sharded(pipeline, lefts: torch.Tensor, rights: torch.Tensor, group=
     a, b = pair_shard(n, rank, world)
     if b > a:
         local = pipeline.estimate(lefts[a:b], rights[a:b])
+        # The gather hands this rank's maps to everybody: the one place where an invalid result
+        # (status word of the tiled aggregation: its row sweeps did not have the device's CUs to
+        # themselves) must not pass.  Recovery as the C ABI documents it: the paired form.
+        status = getattr(pipeline, "status", None)
+        if callable(status) and status():
+            import warnings
+            warnings.warn("stereomatch: tiled aggregation reported status %d on rank %d; "
+                          "recomputing this shard with the paired form" % (status(), rank))
+            agg = pipeline.aggregation
+            form, agg.form = agg.form, "paired"
+            try:
+                local = pipeline.estimate(lefts[a:b], rights[a:b])
+            finally:
+                agg.form = form
     else:
         # Fewer pairs than ranks: this rank owns none.  It still takes part in the gather
         # (with a zero-length block), otherwise the other ranks would wait for it for ever.

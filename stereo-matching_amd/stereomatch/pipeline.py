@@ -41,6 +41,15 @@ class Pipeline:
                 and type(self.disparity_reduce) is WinnerTakesAll
                 and self._cost_volume.is_cuda and self._cost_volume.dtype == torch.float32)
 
+    def status(self) -> int:
+        """Status word of the last ``estimate`` (waits for it; 0 = ok).  Only this package's
+        tiled aggregation can report anything else: a set bit means that call's disparity map
+        is invalid and should be recomputed with ``Semiglobal(form="paired")`` (aggregation.py,
+        "status word").  ``estimate`` itself never blocks; it raises for a failed previous
+        call as soon as that call's word has reached the host."""
+        status = getattr(self.aggregation, "status", None)
+        return int(status()) if callable(status) else 0
+
     def estimate(self, left_image: torch.Tensor, right_image: torch.Tensor) -> torch.Tensor:
         self._cost_volume = self.cost(left_image, right_image, cost_volume=self._cost_volume)
         if self.aggregation is None:

@@ -1,0 +1,229 @@
+"""Robustness of the tiled form of the semiglobal aggregation: the STM_SGM_ACCUMULATE flag
+(what the reference-side stub of INTEGRATION.md passes), the fall-back to the paired form for
+pointers the tiled form cannot take, graph capture, two tiled calls in flight on one device,
+and the status word when something else holds the device's CUs -- a tiled call either
+produces the paired form's bits or reports it, never a wrong map with status 0."""
+import ctypes
+import os
+import subprocess
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_parity import _gpu, _random_volume, assert_same_bits
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _raw_sgm(lib, native, C, I, out, flags, fused_disp=None, ws_slack=0):
+    """stm_sgm_f32 / stm_sgm_wta_f32 through the C ABI on torch tensors; returns the workspace."""
+    B = C.shape[0] if C.dim() == 4 else 1
+    H, W, D = C.shape[-3:]
+    n = int(lib.stm_sgm_workspace_bytes(H, W, D, B, flags))
+    ws = torch.empty(max(n, 16) + ws_slack, dtype=torch.uint8, device=C.device)
+    s = torch.cuda.current_stream().cuda_stream
+    if fused_disp is None:
+        rc = lib.stm_sgm_f32(C.data_ptr(), I.data_ptr(), out.data_ptr(), H, W, D, 0.5, 3.0, flags,
+                             ws.data_ptr(), n, B, s)
+    else:
+        rc = lib.stm_sgm_wta_f32(C.data_ptr(), I.data_ptr(), out.data_ptr(), fused_disp.data_ptr(), H, W, D,
+                                 0.5, 3.0, flags, ws.data_ptr(), n, B, s)
+    native.check(rc)
+    return ws
+
+
+@pytest.mark.parametrize("H,W,D", [(20, 22, 64), (40, 90, 128), (90, 40, 128), (35, 50, 256), (17, 15, 64),
+                                   (33, 129, 128), (64, 80, 128)])
+@pytest.mark.parametrize("form", ["tiled", "paired"])
+def test_accumulate_matches_reference_semantics(device, oracle, H, W, D, form):
+    """STM_SGM_ACCUMULATE: out = (((out0 + L>) + L<) + ...) on top of the caller's contents
+    (the reference's `+=` into its output tensor), in both forms, sum and fused reduction."""
+    from stereomatch import _native
+    lib = _native.lib()
+    rng = np.random.default_rng(H * 31 + W + D)
+    C = _random_volume(rng, H, W, D, "float")
+    image = rng.integers(0, 5, size=(H, W)).astype(np.float32)
+    init = (rng.random((H, W, D)) * 40).astype(np.float32)
+    want = oracle.sgm(C, image, 0.5, 3.0, out=init)
+    flags = _native.STM_SGM_ACCUMULATE | _native.STM_SGM_FORMS[form]
+    assert lib.stm_sgm_uses_tiles(H, W, D, 1, flags) == (1 if form == "tiled" else 0)
+    Cg, Ig = _gpu(C, device), _gpu(image, device)
+    out = _gpu(init, device)
+    _raw_sgm(lib, _native, Cg, Ig, out, flags)
+    assert_same_bits(out.cpu().numpy(), want, form + " accumulate")
+    # pre-zeroed output + ACCUMULATE = what the reference wrapper does (aggregation.py:51)
+    out = torch.zeros_like(Cg)
+    _raw_sgm(lib, _native, Cg, Ig, out, flags)
+    assert_same_bits(out.cpu().numpy(), oracle.sgm(C, image, 0.5, 3.0), form + " accumulate on zeros")
+    # fused reduction on top of the caller's contents, sum kept and not kept
+    for keep in (_native.STM_SGM_KEEP_SUM, 0):
+        out = _gpu(init, device)
+        disp = torch.empty((H, W), dtype=torch.int32, device=device)
+        _raw_sgm(lib, _native, Cg, Ig, out, flags | keep, fused_disp=disp)
+        assert_same_bits(disp.cpu().numpy(), oracle.wta(want), form + " accumulate, fused")
+        if keep:
+            assert_same_bits(out.cpu().numpy(), want, form + " accumulate, fused, kept sum")
+
+
+def test_auto_form_takes_misaligned_pointers(device, oracle):
+    """The library's own choice of the tiled form must not turn a call the paired form accepts
+    into an error: an output (or workspace) that is not 16-byte aligned falls back to the
+    paired form behind the same workspace header; forcing STM_SGM_TILED keeps the error."""
+    from stereomatch import _native
+    lib = _native.lib()
+    H, W, D, B = 64, 320, 128, 40
+    assert lib.stm_sgm_uses_tiles(H, W, D, B, 0) == 1, "shape no longer selects the tiled form by itself"
+    rng = np.random.default_rng(5)
+    C = np.stack([_random_volume(rng, H, W, D, "float") for _ in range(B)])
+    image = rng.integers(0, 5, size=(B, H, W)).astype(np.float32)
+    Cg, Ig = _gpu(C, device), _gpu(image, device)
+    want = torch.empty_like(Cg)
+    _raw_sgm(lib, _native, Cg, Ig, want, _native.STM_SGM_FORMS["paired"])
+    backing = torch.empty(Cg.numel() + 1, dtype=torch.float32, device=device)
+    out = backing[1:].view(Cg.shape)  # 4 bytes off a 16-byte boundary
+    assert out.data_ptr() % 16 == 4
+    ws = _raw_sgm(lib, _native, Cg, Ig, out, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int32), want.view(torch.int32))
+    assert int(ws[:4].view(torch.int32).item()) == 0, "status word behind the fallback"
+    with pytest.raises(RuntimeError, match="16-byte aligned"):
+        _raw_sgm(lib, _native, Cg, Ig, out, _native.STM_SGM_FORMS["tiled"])
+    # the same through the package: an offset view as the reuse tensor
+    import stereomatch
+    sgm = stereomatch.aggregation.Semiglobal(0.5, 3.0)
+    got = sgm(Cg, Ig, out)
+    assert got.data_ptr() == out.data_ptr() and sgm.status() == 0
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+
+
+def test_tiled_pipeline_can_be_captured_into_a_graph(device, oracle):
+    """The tiled form inside a captured graph (its sweeps then use the plain launch), replayed
+    on new inputs; the status word is read through status()."""
+    import stereomatch
+    H, W, D, B = 48, 72, 128, 3
+    pipe = stereomatch.Pipeline(stereomatch.cost.SSD(D), stereomatch.disparity_reduce.WinnerTakesAll(),
+                                stereomatch.aggregation.Semiglobal(form="tiled"))
+    pairs = [oracle.synthetic_pair(H, W, seed=s) for s in range(2 * B)]
+    L = torch.from_numpy(np.stack([p[0] for p in pairs[:B]])).to(device)
+    R = torch.from_numpy(np.stack([p[1] for p in pairs[:B]])).to(device)
+    pipe.estimate(L, R)  # allocates outputs and workspace outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = pipe.estimate(L, R)
+    L.copy_(torch.from_numpy(np.stack([p[0] for p in pairs[B:]])))
+    R.copy_(torch.from_numpy(np.stack([p[1] for p in pairs[B:]])))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert pipe.status() == 0
+    for b in range(B):
+        l, r = pairs[B + b]
+        assert_same_bits(out[b].cpu().numpy(), oracle.wta(oracle.sgm(oracle.ssd(l, r, D), l)), "graph replay %d" % b)
+
+
+def _two_stream_case(device, form):
+    import stereomatch
+    H, W, D, B = 120, 300, 128, 24
+    rng = np.random.default_rng(17)
+    Cs = [torch.from_numpy((rng.random((B, H, W, D)) * 50).astype(np.float32)).to(device) for _ in range(2)]
+    Is = [torch.from_numpy(rng.integers(0, 6, size=(B, H, W)).astype(np.float32)).to(device) for _ in range(2)]
+    ref = [stereomatch.aggregation.Semiglobal(form="paired").aggregate_and_reduce(C, I)[1] for C, I in zip(Cs, Is)]
+    torch.cuda.synchronize()
+    ops = [stereomatch.aggregation.Semiglobal(form=form) for _ in range(2)]
+    streams = [torch.cuda.Stream(device) for _ in range(2)]
+    outs = [None, None]
+    for rep in range(3):
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                outs[k] = ops[k].aggregate_and_reduce(Cs[k], Is[k])[1]
+    torch.cuda.synchronize()
+    return ops, outs, ref
+
+
+def test_two_tiled_calls_in_flight_never_give_a_wrong_map_silently(device):
+    """Two tiled aggregations on two streams of one device.  Cooperative sweep launches are
+    serialised by the runtime, so both normally succeed; whatever happens, each result either
+    equals the paired form's or its status word is set."""
+    ops, outs, ref = _two_stream_case(device, "tiled")
+    t0 = time.time()
+    for k in range(2):
+        st = ops[k].status()
+        if st == 0:
+            assert torch.equal(outs[k], ref[k]), "status 0 but a wrong disparity map (stream %d)" % k
+        else:
+            with pytest.raises(RuntimeError, match="invalid"):
+                ops[k].check()
+    assert time.time() - t0 < 60
+
+
+def _hold_lib():
+    """tests/helpers/libstm_hold.so: a kernel that occupies CUs for a given time (test helper,
+    built by __graft_entry__.build(); not part of the product library)."""
+    path = os.path.join(ROOT, "tests", "helpers", "libstm_hold.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "helpers")])
+    lib = ctypes.CDLL(path)
+    lib.stm_test_hold_cus.restype = ctypes.c_int
+    lib.stm_test_hold_cus.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    return lib
+
+
+@pytest.mark.parametrize("hold_ms,fraction", [(300, 1.0), (300, 0.5), (3500, 0.5)])
+def test_tiled_call_beside_a_kernel_that_holds_cus(device, hold_ms, fraction):
+    """A long-running kernel on a second stream takes the LDS of all / half of the CUs while a
+    tiled aggregation is launched.  Held for 0.3 s the sweeps simply start late (status 0,
+    right bits); held for 3.5 s -- longer than the sweeps' bounded waits -- the call reports
+    it: status word set, check() raises, the next call raises.  Never a wrong map with status 0."""
+    import stereomatch
+    hold = _hold_lib()
+    H, W, D, B = 96, 640, 128, 26  # 10 strips x 26 images: one sweep launch on (almost) every CU
+    rng = np.random.default_rng(23)
+    C = torch.from_numpy((rng.random((B, H, W, D)) * 50).astype(np.float32)).to(device)
+    I = torch.from_numpy(rng.integers(0, 6, size=(B, H, W)).astype(np.float32)).to(device)
+    ref = stereomatch.aggregation.Semiglobal(form="paired").aggregate_and_reduce(C, I)[1]
+    sgm = stereomatch.aggregation.Semiglobal(form="tiled")
+    warm = sgm.aggregate_and_reduce(C, I)[1]
+    assert sgm.status() == 0 and torch.equal(warm, ref)
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    side = torch.cuda.Stream(device)
+    torch.cuda.synchronize()
+    assert hold.stm_test_hold_cus(int(cus * fraction), hold_ms, side.cuda_stream) == 0
+    time.sleep(0.05)  # the holder is running before the aggregation is launched
+    out = sgm.aggregate_and_reduce(C, I)[1].clone()
+    st = sgm.status()
+    torch.cuda.synchronize()
+    if st == 0:
+        assert torch.equal(out, ref), "status 0 but a wrong disparity map"
+    else:
+        assert st & 1
+        with pytest.raises(RuntimeError, match="invalid"):
+            sgm.check()
+    if hold_ms < 1000:
+        assert st == 0, "a 0.3 s hold is far inside the sweeps' 2 s bounded waits"
+    # recovery as documented: the paired form
+    again = stereomatch.aggregation.Semiglobal(form="paired").aggregate_and_reduce(C, I)[1]
+    assert torch.equal(again, ref)
+
+
+def test_failed_call_is_reported_by_the_next_call(device):
+    """The deferred report: a set status word raises at the start of the next call on the same
+    op (no blocking), with the recovery named."""
+    import stereomatch
+    H, W, D, B = 40, 90, 128, 2
+    rng = np.random.default_rng(3)
+    C = torch.from_numpy((rng.random((B, H, W, D)) * 50).astype(np.float32)).to(device)
+    I = torch.from_numpy(rng.integers(0, 6, size=(B, H, W)).astype(np.float32)).to(device)
+    sgm = stereomatch.aggregation.Semiglobal(form="tiled")
+    sgm(C, I)
+    assert sgm.status() == 0
+    sgm(C, I)
+    torch.cuda.synchronize()
+    sgm._status_host.fill_(1)  # what a timed-out sweep would have left in the word
+    with pytest.raises(RuntimeError, match="form='paired'"):
+        sgm(C, I)
+    sgm(C, I)  # the report is delivered once
+    assert sgm.status() == 0
