@@ -111,6 +111,7 @@ int stm_birchfield_ex_f32(const float *left, const float *right, float *cost,
  *                       reference semantics on a pre-zeroed tensor).  Without
  *                       it `out` is overwritten, which is identical to
  *                       accumulating into zeros and saves one read of `out`.
+ *                       Both forms (paired, tiled) implement it.
  */
 #define STM_SGM_ACCUMULATE 1
 /*   STM_SGM_SINGLE_PASSES  run the eight direction families as eight separate passes over
@@ -141,33 +142,47 @@ int stm_birchfield_ex_f32(const float *left, const float *right, float *cost,
 #define STM_SGM_EXACT_NONFINITE 32
 /* Form selection.  By default the library picks per call between the paired form (a wave
  * per path; any shape) and the tiled form (row sweeps + 8x8-pixel tiles: the cost volume is
- * read five times, the sum never travels: 32-36 instead of 56-60 bytes per element; covers
- * D = 64, 128 or 256 without ACCUMULATE / SINGLE_PASSES / EXACT_NONFINITE, chosen by default
- * for D >= 128 with enough columns in the batch to fill the chip).  Same results bit for bit.
+ * read four or five times, the sum never travels: 30-36 instead of 56-60 bytes per element;
+ * covers D = 64, 128 or 256 without SINGLE_PASSES / EXACT_NONFINITE, chosen by default for
+ * D >= 128 with enough columns in the batch to fill the chip).  Same results bit for bit.
  *   STM_SGM_PAIRED  never use the tiled form.
- *   STM_SGM_TILED   use the tiled form whenever it covers the call, whatever the batch size.
+ *   STM_SGM_TILED   use the tiled form whenever it covers the call, whatever the batch size
+ *                   (pointers must then be 16-byte aligned: STM_EINVAL otherwise; when the
+ *                   library chooses the form itself, a call with unaligned pointers takes the
+ *                   paired form instead).
  * Both flags must be passed identically to stm_sgm_workspace_bytes().
  *
- * Workspace header: the first 32-bit word of the workspace is a status word, zeroed at the
- * start of every call that uses the tiled form.  Its row sweeps exchange boundary values
- * between resident workgroups inside one launch; every such wait is bounded (~2 s), and a
- * wait that expires sets bit 0 (the results of that call are then invalid).  It can only
- * happen when the launch's workgroups cannot all be resident (e.g. the device is shared with
- * another long-running kernel).  The entry points never synchronise, so the word is for the
- * caller to inspect after its next synchronisation (stm_sgm_status).
- * Run at most ONE tiled aggregation at a time per device: two of them in flight together (two
- * streams, or two processes on one GPU) can each hold a part of the CUs and wait for the
- * other's until both time out.  Calls on one stream, other kernels beside it, and the paired
- * form are unaffected. */
+ * Residency contract of the tiled form.  Its row sweeps exchange boundary values between the
+ * workgroups of one launch, which must all be resident at once.  The library guarantees its
+ * part: a sweep launch never has more workgroups than the device has CUs and the tiled form
+ * is only ever selected when one sweep workgroup fits a CU (registers, LDS; the runtime's
+ * occupancy calculator is asked).  The caller's part: while a tiled call runs, nothing else
+ * holds CUs of the device for SECONDS -- no second tiled aggregation on another stream or in
+ * another process, no persistent kernel.  Short kernels beside it (a copy, an RCCL
+ * collective, other stereomatch ops) only delay it.  Every wait inside the sweeps is bounded
+ * (~2 s); a wait that expires sets bit 0 of the STATUS WORD, the first 32-bit word of the
+ * workspace (zeroed at the start of every call for which stm_sgm_uses_tiles() is 1), the wave
+ * stops waiting, the call finishes and its results are INVALID.  The entry points never
+ * synchronise, so the word is for the caller to read after its next synchronisation
+ * (stm_sgm_status); RECOVERY: run the call again with STM_SGM_PAIRED, which needs nothing of
+ * the sort.  The Python package does all of this (Semiglobal.status / check, Pipeline.status,
+ * distributed.estimate_sharded re-runs a failed shard with the paired form).
+ *   STM_SGM_COOPERATIVE  launch the sweeps with hipLaunchCooperativeKernel: the runtime
+ *                   validates the grid against the kernel's occupancy and runs cooperative
+ *                   launches one at a time per device, so tiled calls from several streams of
+ *                   one process are safe beside each other.  Costs ~60 us per sweep launch and
+ *                   the call's asynchrony (the runtime waits on the host for the stream's
+ *                   earlier work before such a launch); ignored during stream capture. */
 #define STM_SGM_PAIRED 64
 #define STM_SGM_TILED 128
+#define STM_SGM_COOPERATIVE 256
 size_t stm_sgm_workspace_bytes(int H, int W, int D, int batch, int flags);
-/* Byte offset and meaning of the status word inside a workspace: *(uint32_t*)workspace after
- * the stream has been synchronised; 0 = ok.  Returns the word's value given a HOST copy of
- * the workspace's first 4 bytes (a helper for bindings that cannot cast). */
-/* 1 when stm_sgm_f32 / stm_sgm_wta_f32 will use the tiled form for this call on the current
- * device (and the workspace therefore starts with the status word), else 0. */
+/* 1 when stm_sgm_f32 / stm_sgm_wta_f32 select the tiled form for this shape on the current
+ * device, i.e. the workspace starts with the status word (a 256-byte header; also when such
+ * a call then takes the paired form because of unaligned pointers), else 0. */
 int stm_sgm_uses_tiles(int H, int W, int D, int batch, int flags);
+/* The status word's value given a HOST copy of the workspace's first 4 bytes (a helper for
+ * bindings that cannot cast); 0 = ok. */
 #define STM_SGM_STATUS_TIMEOUT 1u
 unsigned stm_sgm_status(const void *host_copy_of_first_word);
 int stm_sgm_f32(const float *cost, const float *left, float *out, int H, int W,

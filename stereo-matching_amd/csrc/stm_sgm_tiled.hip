@@ -102,10 +102,10 @@ __device__ __forceinline__ u64 *mbox_ptr(float *ws, const TiledGeom &G, int swee
 // two mailboxes per strip edge and row turned into a tenth of the stage's write traffic.
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 constexpr int kAuxSc1 = 16;  // cache-policy bits of the raw buffer builtins: sc1 (write-through / L2-served)
-// The same for the mailbox traffic itself: bit 31 marks the access volatile for the compiler (it
-// is not an instruction bit), so a polling load is re-issued on every trip of a wait loop and a
-// publishing store is never merged or dropped.
-constexpr int kAuxMbox = (int)(0x80000000u | (unsigned)kAuxSc1);
+// The polling loads are re-issued on every trip of a wait loop because the loop carries a
+// compiler memory barrier (mbox_wait); tests/test_abi.py checks the generated code for it.
+// (Marking the accesses volatile for the compiler -- aux bit 31 -- would do the same, but the
+// backend then also widens their scope to sc0 sc1, system scope.)
 
 template <int VPL>
 __device__ __forceinline__ void mbox_publish(u64 *box, int D, int d0, unsigned row, const Row<VPL> &r) {
@@ -118,7 +118,7 @@ __device__ __forceinline__ void mbox_publish(u64 *box, int D, int d0, unsigned r
       v4u_t q;
       q.x = __builtin_bit_cast(unsigned, r.v[j]); q.y = tag;
       q.z = __builtin_bit_cast(unsigned, r.v[j + 1]); q.w = tag;
-      __builtin_amdgcn_raw_buffer_store_b128(q, rs, (d0 + j) * 8, 0, kAuxMbox);
+      __builtin_amdgcn_raw_buffer_store_b128(q, rs, (d0 + j) * 8, 0, kAuxSc1);
     }
   } else {
 #pragma unroll
@@ -141,7 +141,7 @@ __device__ __forceinline__ void mbox_peek(const u64 *box, int D, int d0, unsigne
     const BufRsrc rs = make_rsrc(slot - d0, (unsigned)(D * sizeof(u64)));
 #pragma unroll
     for (int j = 0; j < VPL; j += 2) {
-      const v4u_t g = __builtin_amdgcn_raw_buffer_load_b128(rs, (d0 + j) * 8, 0, kAuxMbox);
+      const v4u_t g = __builtin_amdgcn_raw_buffer_load_b128(rs, (d0 + j) * 8, 0, kAuxSc1);
       q.val[j] = g.x; q.tag[j] = g.y;
       q.val[j + 1] = g.z; q.tag[j + 1] = g.w;
     }
@@ -239,25 +239,30 @@ struct SweepArgs {
 #define STM_SWEEP_STAMP(k) do {} while (0)
 #endif
 
+// The exchange slots of a sweep workgroup: [parity][A/B][wave or half-wave][d].  At D = 128 the
+// interior waves step two columns per half-wave (sgm_step_h2x3): the unit of the exchange is then
+// the half-wave, and the other waves follow that numbering.
+template <int VPL>
+struct SweepXch {
+  static constexpr int NV = VPL == 2 ? 2 * kSweepWaves : kSweepWaves;
+  float v[2][2][NV][64 * VPL];
+};
+
+// One image's sweep for this workgroup's column strip.
 template <int VPL, int CW, bool UP>
-__global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float *__restrict__ cost_all,
-                                                                    const float *__restrict__ image_all,
-                                                                    float *__restrict__ ws,
-                                                                    const SweepArgs P) {
+__device__ __forceinline__ void sweep_image(const float *__restrict__ cost_all, const float *__restrict__ image_all,
+                                            float *__restrict__ ws, const SweepArgs &P, const int b,
+                                            float (&xch)[2][2][SweepXch<VPL>::NV][64 * VPL], bool &dead) {
   static_assert(CW >= 2, "a wave's leaving states must not depend on its arriving ones");
   constexpr int PF = 2;  // cost rows in flight beyond the current one
   constexpr int NW = kSweepWaves;
   constexpr int D = 64 * VPL;
-  // At D = 128 the interior waves step two columns per half-wave (sgm_step_h2x3): the unit of
-  // the exchange is then the half-wave, and the other waves follow that numbering.
   constexpr bool H2 = VPL == 2;
-  constexpr int NV = H2 ? 2 * NW : NW;
-  __shared__ __attribute__((aligned(16))) float xch[2][2][NV][D];  // [parity][A/B][wave or half-wave][d]
+  constexpr int NV = SweepXch<VPL>::NV;
   const TiledGeom &G = P.G;
   const int lane = threadIdx.x & 63;
   const int wv = wave_uniform((int)(threadIdx.x >> 6));
   const int s = blockIdx.x;
-  const int b = P.b0 + (int)blockIdx.y;
   const int H = G.H, W = G.W;
   const int d0 = lane * VPL;
   const int xa = (s * NW + wv) * CW;  // this wave's first column
@@ -277,7 +282,6 @@ __global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float
   u64 *pubB = (has_left && !left_lds) ? mbox_ptr(ws, G, sweep, b, s, 1) : nullptr;
   const u64 *subA = (has_left && !left_lds) ? mbox_ptr(ws, G, sweep, b, s - 1, 0) : nullptr;
   const u64 *subB = (has_right && !right_lds) ? mbox_ptr(ws, G, sweep, b, s + 1, 1) : nullptr;
-  bool dead = false;
   // Exchange slots: where this wave's leaving A / B go and where its arriving ones come from.
   const int slot_pubA = H2 ? 2 * wv + 1 : wv, slot_pubB = H2 ? 2 * wv : wv;
   const int slot_subA = H2 ? 2 * wv - 1 : wv - 1, slot_subB = H2 ? 2 * wv + 2 : wv + 1;
@@ -717,6 +721,21 @@ __global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float
   }
 }
 
+// One launch sweeps the images P.b0 .. P.b0 + gridDim.y - 1 (never more workgroups than the
+// device has CUs: make_plan).  A persistent form -- one launch per direction, every workgroup
+// taking image after image -- was measured and lost 7-12 %: the loop over images costs the
+// kernel the few registers it has left, and a spilled value reloaded in the row loop drains
+// every cost-row prefetch in flight (s_waitcnt vmcnt(0)) once per row.
+template <int VPL, int CW, bool UP>
+__global__ __launch_bounds__(kSweepWaves * 64) void sgm_sweep_kernel(const float *__restrict__ cost_all,
+                                                                    const float *__restrict__ image_all,
+                                                                    float *__restrict__ ws,
+                                                                    const SweepArgs P) {
+  __shared__ __attribute__((aligned(16))) SweepXch<VPL> xch;
+  bool dead = false;  // a bounded wait of this wave has expired: it never waits again
+  sweep_image<VPL, CW, UP>(cost_all, image_all, ws, P, P.b0 + (int)blockIdx.y, xch.v, dead);
+}
+
 // =====================================================================================
 // Horizontal walks: one wave per image row and direction; the state is kept where the path
 // leaves a tile (x % 8 == 7 going right, x % 8 == 0 going left).
@@ -966,6 +985,66 @@ __device__ __forceinline__ Row<VPL> lds_row(const float *tile, int pix, int d0) 
   return load_row<VPL, true>(tile + (size_t)pix * (64 * VPL), 0, 64 * VPL, d0);
 }
 
+// The sum tile keeps 64 bytes of padding behind every pixel (stride D + 16 floats): the chains'
+// accesses (whole pixels, 16 bytes per lane) do not care, and the winner-takes-all below, whose
+// lanes of one instruction spread over several pixels, then finds them in different banks.
+constexpr int st_stride(int D) { return D + 16; }
+template <int VPL>
+__device__ __forceinline__ Row<VPL> lds_srow(const float *St, int pix, int d0) {
+  return load_row<VPL, true>(St + (size_t)pix * st_stride(64 * VPL), 0, 64 * VPL, d0);
+}
+
+// Winner takes all (src/winners_take_all.cu:21-40) of a finished sum tile in LDS, by all NWAVES
+// waves of the workgroup: a wave takes 64 / NWAVES pixels, LP = NWAVES lanes share a pixel, lane
+// r of them scans the 16-byte chunks r, r + LP, ... in ascending order with the reference's
+// strict '<' (its first minimum; a NaN never wins), then the lanes of a pixel agree on the
+// smallest value and on the lowest index among the lanes holding it.  A NaN at d = 0 wins, as in
+// the reference scan, which starts from it and never replaces it.  The reduction used to sit in
+// the last pair's update, one pixel per (half-)wave: a wave-wide minimum and a second one for
+// the index per pixel, a fifth of the D = 128 tile's time.
+template <int D, int NWAVES>
+__device__ __forceinline__ void tile_wta_lds(const float *St, int wave, int lane, int tw, int th, int W, int x0,
+                                             int y0, int32_t *__restrict__ disp) {
+  static_assert(NWAVES == 4 || NWAVES == 16, "4 or 16 lanes per pixel");
+  constexpr int PPW = 64 / NWAVES, LP = NWAVES, NJ = D / (LP * 4);
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const int pix = wave * PPW + lane / LP, r = lane % LP;
+  const float *p = St + pix * st_stride(D) + r * 4;
+  float best = __builtin_inff();
+  int idxk = 0;  // the winner's index minus r * 4
+  bool nan0 = false;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const v4f q = *reinterpret_cast<const v4f *>(p + j * LP * 4);
+    const float v[4] = {q.x, q.y, q.z, q.w};
+    if (j == 0) nan0 = r == 0 && v[0] != v[0];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool lt = v[e] < best;
+      best = lt ? v[e] : best;
+      idxk = lt ? j * LP * 4 + e : idxk;
+    }
+  }
+  float m = best;
+  m = vmin_f32(m, dpp_f32<0xb1>(m, m));  // quad_perm [1,0,3,2]
+  m = vmin_f32(m, dpp_f32<0x4e>(m, m));  // quad_perm [2,3,0,1]
+  if (LP == 16) {
+    m = vmin_f32(m, dpp_f32<0x141>(m, m));  // row_half_mirror
+    m = vmin_f32(m, dpp_f32<0x140>(m, m));  // row_mirror
+  }
+  int k = best == m ? idxk + r * 4 : 0x7fffffff;
+  k = nan0 ? 0 : k;
+  int t;
+  t = dpp_i32<0xb1>(k, k); k = t < k ? t : k;
+  t = dpp_i32<0x4e>(k, k); k = t < k ? t : k;
+  if (LP == 16) {
+    t = dpp_i32<0x141>(k, k); k = t < k ? t : k;
+    t = dpp_i32<0x140>(k, k); k = t < k ? t : k;
+  }
+  const int px = pix & (kT - 1), py = pix >> 3;
+  if (r == 0 && px < tw && py < th) disp[(size_t)(y0 + py) * W + (x0 + px)] = k;
+}
+
 // The slots of a wave's phase: pixel index (y * 8 + x, tile coordinates) of every slot.
 template <int PHASE>
 struct Slots {
@@ -1076,7 +1155,7 @@ __device__ __forceinline__ void tile_add(const PhaseGeom &g, const Slots<PHASE> 
           for (int j = 0; j < VPL; ++j) acc.v[j] = 0.0f;
         }
       } else {
-        acc = lds_row<VPL>(St, pix, d0);
+        acc = lds_srow<VPL>(St, pix, d0);
       }
       if (PHASE == 2) {
         const int pre = s < nA ? ca.pre : cb.pre;
@@ -1097,25 +1176,12 @@ __device__ __forceinline__ void tile_add(const PhaseGeom &g, const Slots<PHASE> 
           for (int j = 0; j < VPL; ++j) acc.v[j] = acc.v[j] + LI[s].v[j];
         }
       }
-      if (PHASE < 3) {
-        store_row<VPL, true>(St + (size_t)pix * D, 0, D, d0, acc);
-      } else {
+      // The last pair's result leaves as the finished sum and / or stays in the sum tile for the
+      // winner-takes-all that follows the tile's last barrier (tile_wta_lds).
+      if (PHASE < 3 || FINAL != 0) store_row<VPL, true>(St + (size_t)pix * st_stride(D), 0, D, d0, acc);
+      if (PHASE == 3 && FINAL != 2) {
         const size_t q = (size_t)(y0 + (pix >> 3)) * P.G.W + (x0 + (pix & (kT - 1)));
-        if (FINAL != 2) store_row<VPL, true>(out, q, D, d0, acc);
-        if (FINAL != 0) {
-          // Winner takes all (src/winners_take_all.cu:21-40): strict-'<' scan in register
-          // order, then the lowest lane among those holding the wave minimum; a NaN at d = 0
-          // wins, as in the reference scan.
-          float best = __builtin_inff();
-          int idx = d0;
-#pragma unroll
-          for (int j = 0; j < VPL; ++j)
-            if (acc.v[j] < best) { best = acc.v[j]; idx = d0 + j; }
-          const float m = wave_min_f32(best);
-          const int win = __builtin_amdgcn_readlane(idx, __builtin_ctzll(__ballot(best == m)));
-          const float first = read_lane(acc.v[0], 0);
-          if (lane == 0) disp[q] = (first != first) ? 0 : win;
-        }
+        store_row<VPL, true>(out, q, D, d0, acc);
       }
     }
   }
@@ -1189,7 +1255,7 @@ __device__ __forceinline__ void tile_add_fast(const Slots<PHASE> &sl, const Row<
   constexpr int D = 64 * VPL;
   const int d0 = lane * VPL;
   Row<VPL> sn;
-  if (PHASE != 0) sn = lds_row<VPL>(St, sl.pix[0], d0);
+  if (PHASE != 0) sn = lds_srow<VPL>(St, sl.pix[0], d0);
 #pragma unroll
   for (int s = 0; s < kT; ++s) {
     const int pix = sl.pix[s];
@@ -1199,7 +1265,7 @@ __device__ __forceinline__ void tile_add_fast(const Slots<PHASE> &sl, const Row<
       for (int j = 0; j < VPL; ++j) acc.v[j] = 0.0f;
     } else {
       acc = sn;
-      if (s < kT - 1) sn = lds_row<VPL>(St, sl.pix[s + 1], d0);  // the next slot's sum, early
+      if (s < kT - 1) sn = lds_srow<VPL>(St, sl.pix[s + 1], d0);  // the next slot's sum, early
     }
 #pragma unroll
     for (int j = 0; j < VPL; ++j) acc.v[j] = acc.v[j] + LF[s].v[j];
@@ -1207,22 +1273,10 @@ __device__ __forceinline__ void tile_add_fast(const Slots<PHASE> &sl, const Row<
 #pragma unroll
       for (int j = 0; j < VPL; ++j) acc.v[j] = acc.v[j] + LI[s].v[j];
     }
-    if (PHASE < 3) {
-      store_row<VPL, true>(St + (size_t)pix * D, 0, D, d0, acc);
-    } else {
+    if (PHASE < 3 || FINAL != 0) store_row<VPL, true>(St + (size_t)pix * st_stride(D), 0, D, d0, acc);
+    if (PHASE == 3 && FINAL != 2) {
       const size_t q = (size_t)(y0 + (pix >> 3)) * W + (x0 + (pix & (kT - 1)));
-      if (FINAL != 2) store_row<VPL, true>(out, q, D, d0, acc);
-      if (FINAL != 0) {
-        float best = __builtin_inff();
-        int idx = d0;
-#pragma unroll
-        for (int j = 0; j < VPL; ++j)
-          if (acc.v[j] < best) { best = acc.v[j]; idx = d0 + j; }
-        const float m = wave_min_f32(best);
-        const int win = __builtin_amdgcn_readlane(idx, __builtin_ctzll(__ballot(best == m)));
-        const float first = read_lane(acc.v[0], 0);
-        if (lane == 0) disp[q] = (first != first) ? 0 : win;
-      }
+      store_row<VPL, true>(out, q, D, d0, acc);
     }
   }
 }
@@ -1310,7 +1364,7 @@ __global__ __launch_bounds__(2 * kT * 64, VPL >= 4 ? 4 : 8) void sgm_tile_kernel
                                                                float *__restrict__ ws, const TileArgs P) {
   constexpr int D = 64 * VPL;
   __shared__ __attribute__((aligned(16))) float Ct[kT * kT * D];
-  __shared__ __attribute__((aligned(16))) float St[kT * kT * D];
+  __shared__ __attribute__((aligned(16))) float St[kT * kT * st_stride(D)];
   __shared__ float Ip[(kT + 2) * (kT + 2)];
   const TiledGeom &G = P.G;
   const int lane = threadIdx.x & 63;
@@ -1352,7 +1406,18 @@ __global__ __launch_bounds__(2 * kT * 64, VPL >= 4 ? 4 : 8) void sgm_tile_kernel
       }
       load_entries<VPL, 0>(E0, tile_geom<0>(w, tw, th), border_base(ws, G, t.b), G, x0, y0, d0);
     };
+    // The prefetched cost rows and intensities of tile `t` go to LDS (nobody reads Ct or Ip
+    // between a tile's B3 and the next tile's B0).
+    auto stage = [&](const TileWalk &t) {
+      const int th = imin(kT, G.H - t.trow * kT);
+      if (w < th) {
+#pragma unroll
+        for (int c = 0; c < kT; ++c) store_row<VPL, true>(Ct + (size_t)(w * kT + c) * D, 0, D, d0, cpre[c]);
+      }
+      if (threadIdx.x < (kT + 2) * (kT + 2)) Ip[threadIdx.x] = ipre;
+    };
     prefetch(next_t);
+    stage(next_t);
     for (; id < ntiles; id += stride) {
       const int b = cur_t.b, x0 = cur_t.tcol * kT, y0 = cur_t.trow * kT;
       const int tw = imin(kT, G.W - x0), th = imin(kT, G.H - y0);
@@ -1363,11 +1428,6 @@ __global__ __launch_bounds__(2 * kT * 64, VPL >= 4 ? 4 : 8) void sgm_tile_kernel
       const int tile = id < 4096 ? id : 4096;
 #endif
       STM_STAMP(0);
-      if (w < th) {
-#pragma unroll
-        for (int c = 0; c < kT; ++c) store_row<VPL, true>(Ct + (size_t)(w * kT + c) * D, 0, D, d0, cpre[c]);
-      }
-      if (threadIdx.x < (kT + 2) * (kT + 2)) Ip[threadIdx.x] = ipre;
       const Entries<VPL, 0> E0now = E0;
       STM_STAMP(1);
       lds_barrier();  // B0
@@ -1387,8 +1447,13 @@ __global__ __launch_bounds__(2 * kT * 64, VPL >= 4 ? 4 : 8) void sgm_tile_kernel
       STM_STAMP(6);
       if (id + stride < ntiles) next_t.next(G);
       prefetch(next_t);
-      cur_t = next_t;
       lds_barrier();  // B3
+      stage(next_t);  // (while group 1 runs its last update)
+      if constexpr (FINAL != 0) {
+        lds_barrier();  // B4: the finished sum tile is complete
+        tile_wta_lds<D, 2 * kT>(St, w16, lane, tw, th, G.W, x0, y0, disp);
+      }
+      cur_t = next_t;
       STM_STAMP(7);
     }
   } else {
@@ -1430,6 +1495,10 @@ __global__ __launch_bounds__(2 * kT * 64, VPL >= 4 ? 4 : 8) void sgm_tile_kernel
         lds_barrier();  // B3
         STM_STAMP(6);
       });
+      if constexpr (FINAL != 0) {
+        lds_barrier();  // B4
+        tile_wta_lds<D, 2 * kT>(St, w16, lane, tw, th, G.W, x0, y0, disp);
+      }
       cur_t = next_t;
       STM_STAMP(7);
     }
@@ -1654,9 +1723,15 @@ __device__ __forceinline__ void h2_pair(const H2Pair &K, const Row<4> (&E)[4], i
   }
   const bool counted = PHASE >= 2 && cls == 3;
   const int a0 = K.pix0 * kPixBytes + hl16, a1 = K.pix1 * kPixBytes + hl16;
-  auto addr = [&](auto s_) {  // LDS byte address of slot s (the slot part is an immediate)
+  auto addr = [&](auto s_) {  // LDS byte address of slot s in the cost tile (the slot part is an immediate)
     constexpr int s = decltype(s_)::value;
     return s < NA ? a0 + s * pstep * kPixBytes : a1 + (s - NA) * pstep * kPixBytes;
+  };
+  constexpr int kSumPixBytes = st_stride(128) * 4;  // the sum tile's pixels are padded (st_stride)
+  const int sa0 = K.pix0 * kSumPixBytes + hl16, sa1 = K.pix1 * kSumPixBytes + hl16;
+  auto saddr = [&](auto s_) {  // ... and in the sum tile
+    constexpr int s = decltype(s_)::value;
+    return s < NA ? sa0 + s * pstep * kSumPixBytes : sa1 + (s - NA) * pstep * kSumPixBytes;
   };
   Row<4> LF[kT], LI[kT];
   Row<4> pf = E[0];
@@ -1706,49 +1781,26 @@ __device__ __forceinline__ void h2_pair(const H2Pair &K, const Row<4> (&E)[4], i
       }
     }
     acc.v[0] = lo.x; acc.v[1] = lo.y; acc.v[2] = hi.x; acc.v[3] = hi.y;
-    if (PHASE < 3) h2_lds_store(St, addr(s_), acc);
+    // (pair 3: the finished sum stays in the sum tile for the winner-takes-all behind the tile's
+    // last barrier, tile_wta_lds)
+    if (PHASE < 3 || FINAL != 0) h2_lds_store(St, saddr(s_), acc);
   };
-  // Pair 3: the results of two slots leave -- the sums and / or their winners.  Winner takes
-  // all per half (src/winners_take_all.cu:21-40): strict-'<' scan in register order, then the
-  // lowest lane of the half among those holding its minimum; a NaN at d = 0 wins, as in the
-  // reference scan.  Without leaving the vector unit: the lanes holding the half's minimum
-  // offer their index, the others INT_MAX, a NaN at d = 0 offers -1; minimum over the half.
+  // Pair 3: the finished sums of two slots leave (unless only their winners are wanted).
   auto finish2 = [&](auto sa_, const Row<4> &ra, auto sb_, const Row<4> &rb) {
-    if constexpr (PHASE == 3) {
+    if constexpr (PHASE == 3 && FINAL != 2) {
       constexpr int sa = decltype(sa_)::value, sb = decltype(sb_)::value;
       const int d0 = hl16 >> 2;
       const int pa = sa < NA ? K.pix0 + sa * pstep : K.pix1 + (sa - NA) * pstep;
       const int pb = sb < NA ? K.pix0 + sb * pstep : K.pix1 + (sb - NA) * pstep;
       const unsigned qa = (unsigned)((y0 + (pa >> 3)) * W + (x0 + (pa & (kT - 1))));  // < H * W
       const unsigned qb = (unsigned)((y0 + (pb >> 3)) * W + (x0 + (pb & (kT - 1))));
-      if (FINAL != 2) {
-        store_row<4, true>(out, (size_t)qa, 128, d0, ra);
-        store_row<4, true>(out, (size_t)qb, 128, d0, rb);
-      }
-      if (FINAL != 0) {
-        float ba = __builtin_inff(), bb = __builtin_inff();
-        int ia = d0, ib = d0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (ra.v[j] < ba) { ba = ra.v[j]; ia = d0 + j; }
-          if (rb.v[j] < bb) { bb = rb.v[j]; ib = d0 + j; }
-        }
-        float ma = ba, mb = bb;
-        half_min2_f32(ma, mb);
-        int ka = ba == ma ? ia : 0x7fffffff, kb = bb == mb ? ib : 0x7fffffff;
-        if (hl16 == 0 && ra.v[0] != ra.v[0]) ka = -1;
-        if (hl16 == 0 && rb.v[0] != rb.v[0]) kb = -1;
-        half_min2_i32(ka, kb);
-        if ((lane & 31) == 0) {
-          disp[qa] = ka < 0 ? 0 : ka;
-          disp[qb] = kb < 0 ? 0 : kb;
-        }
-      }
+      store_row<4, true>(out, (size_t)qa, 128, d0, ra);
+      store_row<4, true>(out, (size_t)qb, 128, d0, rb);
     }
   };
   auto sum_of = [&](auto s_) {
     Row<4> r;
-    if (PHASE != 0) r = h2_lds_row(St, addr(s_));
+    if (PHASE != 0) r = h2_lds_row(St, saddr(s_));
     else r = E[0];  // (unused: any defined value)
     return r;
   };
@@ -1904,7 +1956,7 @@ __global__ __launch_bounds__(4 * 64, 2) void sgm_tile_h2_kernel(const float *__r
                                                                  float *__restrict__ ws, const TileArgs P) {
   constexpr int D = 128;
   __shared__ __attribute__((aligned(16))) float Ct[kT * kT * D];
-  __shared__ __attribute__((aligned(16))) float St[kT * kT * D];
+  __shared__ __attribute__((aligned(16))) float St[kT * kT * st_stride(D)];
   __shared__ float Ip[(kT + 2) * (kT + 2)];
   const TiledGeom &G = P.G;
   const int lane = threadIdx.x & 63;
@@ -2062,6 +2114,9 @@ __global__ __launch_bounds__(4 * 64, 2) void sgm_tile_h2_kernel(const float *__r
     }
     lds_barrier();
     STM_STAMP(7);
+    // Winner takes all of the finished sum tile (sixteen pixels per wave); the next tile's
+    // first update of the sum tile lies behind its staging barrier.
+    if constexpr (FINAL != 0) tile_wta_lds<D, 4>(St, w, lane, tw, th, G.W, x0, y0, disp);
     if (!more) break;
     cur_t = next_t;
   }
@@ -2126,22 +2181,28 @@ bool make_plan(int H, int W, int D, int batch, TiledPlan &plan) {
 }
 
 // Launches one row sweep.  Its workgroups wait for each other, so all of them must be resident
-// together: the launch is a COOPERATIVE one (hipLaunchCooperativeKernel), which the runtime
-// refuses when the grid exceeds what the device can hold at once for this kernel (registers,
-// LDS, a CU mask) instead of letting the waits run into their timeouts; make_plan() has sized
-// the grid to the CU count and sweep_fits() has checked the kernel's occupancy before.  What a
-// cooperative launch cannot see is a CU that is busy with somebody else's long-running
-// workgroups: the bounded waits and the status word remain the backstop for that.  While the
-// stream is being captured into a graph the plain launch is used (a cooperative launch is not
-// capturable on every runtime); replaying such a graph is under the caller's "nothing else
-// holds the device's CUs" contract.
+// together.  What guarantees that: the grid never has more workgroups than the device has CUs
+// (make_plan), one workgroup of this kernel fits a CU (sweep_fits: registers and LDS, asked from
+// the runtime's occupancy calculator once per device and D; a call for which it does not hold
+// never selects the tiled form), and the CALLER'S CONTRACT that nothing else holds the device's
+// CUs for seconds while the call runs (include/stereomatch_hip.h).  Behind that, every wait is
+// bounded and a wait that expires is reported in the status word.
+//   STM_SGM_COOPERATIVE makes the launch a cooperative one (hipLaunchCooperativeKernel): the
+// runtime then validates the grid against the kernel's occupancy itself and runs cooperative
+// launches one at a time per device, which makes tiled calls from several streams of one
+// process safe beside each other.  The price is why it is not the default: ROCm's runtime takes
+// exclusive access to the device for such a launch -- the host thread waits for the stream's
+// earlier work before it submits -- ~60 us per sweep launch, 1 ms of a 42 ms Teddy batch, and the
+// call is no longer asynchronous.  Not used while the stream is being captured into a graph.
 template <typename Kernel>
-int launch_sweep(Kernel kernel, dim3 grid, dim3 block, hipStream_t s, const float *cost, const float *left,
-                 float *ws, const SweepArgs &A) {
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  const bool capturing = hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
-  static const bool plain = getenv("STM_SWEEP_PLAIN_LAUNCH") != nullptr;  // development: A/B the two launch paths
-  if (capturing || plain) {
+int launch_sweep(Kernel kernel, dim3 grid, dim3 block, hipStream_t s, bool cooperative, const float *cost,
+                 const float *left, float *ws, const SweepArgs &A) {
+  if (cooperative) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) (void)hipGetLastError();
+    if (cap != hipStreamCaptureStatusNone) cooperative = false;
+  }
+  if (!cooperative) {
     hipLaunchKernelGGL(kernel, grid, block, 0, s, cost, left, ws, A);
     return check_launch("stm_sgm_f32 (tiled: row sweep)");
   }
@@ -2181,8 +2242,8 @@ bool sweep_fits(int D) {
 
 template <int VPL>
 int run_tiled(const float *cost, const float *left, float *out, int32_t *disp, const TiledPlan &plan,
-              float p1, float p2, int dlim, int true_paths, int accumulate, float *ws, int batch, hipStream_t s,
-              int final_mode) {
+              float p1, float p2, int dlim, int true_paths, int accumulate, bool cooperative, float *ws, int batch,
+              hipStream_t s, int final_mode) {
   const TiledGeom &G = plan.G;
   if (hipMemsetAsync(ws, 0, plan.zero_bytes, s) != hipSuccess)
     return fail(STM_EHIP, "stm_sgm_f32 (tiled): hipMemsetAsync failed");
@@ -2212,8 +2273,8 @@ int run_tiled(const float *cost, const float *left, float *out, int32_t *disp, c
       const int n = batch - b0 < plan.group ? batch - b0 : plan.group;
       const dim3 grid(G.strips, n), block(kSweepWaves * 64);
       constexpr int CW = 8 / VPL;  // = sweep_cw(VPL)
-      const int rc = up ? launch_sweep(sgm_sweep_kernel<VPL, CW, true>, grid, block, s, cost, left, ws, A)
-                        : launch_sweep(sgm_sweep_kernel<VPL, CW, false>, grid, block, s, cost, left, ws, A);
+      const int rc = up ? launch_sweep(sgm_sweep_kernel<VPL, CW, true>, grid, block, s, cooperative, cost, left, ws, A)
+                        : launch_sweep(sgm_sweep_kernel<VPL, CW, false>, grid, block, s, cooperative, cost, left, ws, A);
       if (rc != STM_OK) return rc;
     }
   }
@@ -2316,11 +2377,12 @@ int sgm_run_tiled(const float *cost, const float *left, float *out, int32_t *dis
   const int dlim = (flags & STM_SGM_FULL_MIN) ? D : D - 1;
   const int true_paths = (flags & STM_SGM_TRUE_PATHS) ? 1 : 0;
   const int acc = (flags & STM_SGM_ACCUMULATE) ? 1 : 0;
+  const bool coop = (flags & STM_SGM_COOPERATIVE) != 0 || getenv("STM_SWEEP_COOPERATIVE") != nullptr;
   float *ws = static_cast<float *>(workspace);
   switch (D / 64) {
-    case 1: return run_tiled<1>(cost, left, out, disp, plan, penalty1, penalty2, dlim, true_paths, acc, ws, batch, stream, final_mode);
-    case 2: return run_tiled<2>(cost, left, out, disp, plan, penalty1, penalty2, dlim, true_paths, acc, ws, batch, stream, final_mode);
-    default: return run_tiled<4>(cost, left, out, disp, plan, penalty1, penalty2, dlim, true_paths, acc, ws, batch, stream, final_mode);
+    case 1: return run_tiled<1>(cost, left, out, disp, plan, penalty1, penalty2, dlim, true_paths, acc, coop, ws, batch, stream, final_mode);
+    case 2: return run_tiled<2>(cost, left, out, disp, plan, penalty1, penalty2, dlim, true_paths, acc, coop, ws, batch, stream, final_mode);
+    default: return run_tiled<4>(cost, left, out, disp, plan, penalty1, penalty2, dlim, true_paths, acc, coop, ws, batch, stream, final_mode);
   }
 }
 

@@ -23,6 +23,7 @@ STM_SGM_FULL_MIN = 8
 STM_SGM_TRUE_PATHS = 16
 STM_SGM_EXACT_NONFINITE = 32
 STM_SGM_FORMS = {"auto": 0, "paired": 64, "tiled": 128}
+STM_SGM_COOPERATIVE = 256
 STM_DP_MODES = {"reference": 0, "corrected": 1}
 STM_BT_INDEXING = {"reference": 0, "padded": 1}
 

@@ -30,7 +30,7 @@ class Semiglobal:
 
     def __init__(self, penalty1: float = 0.1, penalty2: float = 0.2, single_passes: bool = False,
                  paths: str = "reference", full_min: bool = False,
-                 exact_nonfinite: bool = False, form: str = "auto"):
+                 exact_nonfinite: bool = False, form: str = "auto", cooperative: bool = False):
         if paths not in ("reference", "hirschmuller"):
             raise ValueError("Semiglobal paths must be 'reference' or 'hirschmuller'")
         self.penalty1 = penalty1
@@ -48,6 +48,12 @@ class Semiglobal:
         if form not in _native.STM_SGM_FORMS:
             raise ValueError("Semiglobal form must be one of %s" % sorted(_native.STM_SGM_FORMS))
         self.form = form
+        # cooperative=True (STM_SGM_COOPERATIVE): the tiled form's row sweeps are launched as
+        # cooperative kernels, which the runtime runs one at a time per device -- for processes
+        # that run tiled aggregations on several streams of one device.  ~60 us per sweep launch
+        # and the call stops being asynchronous; by default the device is expected to be this
+        # call's while it runs (include/stereomatch_hip.h, "Residency contract").
+        self.cooperative = cooperative
         # False (default): a direction and its inverse share one pass over the sum (less HBM
         # traffic, larger workspace); True: eight separate passes.  Same bits either way.
         self.single_passes = single_passes
@@ -99,6 +105,8 @@ class Semiglobal:
         if self.exact_nonfinite:
             flags |= _native.STM_SGM_EXACT_NONFINITE
         flags |= _native.STM_SGM_FORMS[self.form]
+        if self.cooperative:
+            flags |= _native.STM_SGM_COOPERATIVE
         if fused:
             disparity_img = output_tensor(cost_volume.shape[:-1], torch.int32, device,
                                           reuse=disparity_img)

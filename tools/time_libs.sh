@@ -11,7 +11,7 @@ for SHAPE in "$@"; do
   for L in $TAGS; do
     D=/tmp/tl_${L}_$(echo $SHAPE | tr ' ' _)
     rm -rf $D
-    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o r -- python3 $ROOT/tools/run_lib.py $ROOT/tools/_probe/libstm_$L.so $SHAPE > $D.log 2>&1 || { echo "== $L $SHAPE FAILED" >> $LOG; tail -5 $D.log >> $LOG; exit 1; }
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o r -- python3 $ROOT/tools/run_lib.py $ROOT/tools/_probe/libstm_$L.so $SHAPE > $D.log 2>&1 || { echo "== $L $SHAPE FAILED" >> $LOG; cp $D.log $ROOT/gpurun_out/time_libs_fail_${L}.log; tail -5 $D.log >> $LOG; exit 1; }
     echo "== $L $SHAPE" >> $LOG
     python3 - $D >> $LOG <<'PY'
 import csv, glob, sys
