@@ -1,0 +1,63 @@
+"""Host-side checks of the tiled aggregation's kernels that need no GPU.
+
+* ``tests/host/tiled_index_check.cpp`` evaluates, through the same ``__host__ __device__``
+  functions the kernels call (``csrc/stm_sgm_tiled_index.h``), every global-memory access of the
+  sweep, walk and tile kernels for H, W in {1,2,3,7,8,9,15,16,17,40,95,151,375,450}, D in
+  {64,128,256}, batch in {1,2}, and asserts that each lies inside its buffer (cost volume, image,
+  border-state blocks, mailboxes, outputs), clamped prefetches and dummy entry reads included.
+* The generated code of the sweep kernels re-issues the mailbox load on every trip of a wait
+  loop (the polling load must not be hoisted out of it).
+"""
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "stereo-matching_amd", "csrc")
+
+
+def test_every_tiled_kernel_address_lies_inside_its_buffer(tmp_path):
+    exe = str(tmp_path / "tiled_index_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Werror", "-I", CSRC,
+                           os.path.join(ROOT, "tests", "host", "tiled_index_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    m = re.match(r"(\d+) shapes, (\d+) checks, 0 failures", out.stdout)
+    assert m and int(m.group(1)) == 14 * 14 * 3 * 2 and int(m.group(2)) > 10 ** 9, out.stdout
+
+
+def test_kernels_use_the_index_header_for_their_addresses():
+    """The kernels' files form no border-state or mailbox address by hand: the expressions the
+    range model covers are the only ones (a guard against the model and the kernels drifting
+    apart)."""
+    for name in ("stm_sgm_sweep.hip", "stm_sgm_hwalk.hip", "stm_sgm_tile.hip", "stm_sgm_tile_h2.hip",
+                 "stm_sgm_tile_common.h"):
+        src = open(os.path.join(CSRC, name)).read()
+        code = "\n".join(line.split("//")[0] for line in src.splitlines() if "STM_STAMP" not in line)
+        for pattern in ("* G.nTR +", "* G.nTC +", "nTR + ", "nTC + "):  # ((k * nTR + t) * W + x) * D and friends
+            assert pattern not in code, name + ": border-state index formed by hand (%r)" % pattern
+        assert "kMboxSlots *" not in code and "% kMboxSlots" not in code, name + ": mailbox index formed by hand"
+
+
+def test_mailbox_poll_is_reissued_inside_the_wait_loop(tmp_path):
+    """ISA of the sweep kernels: every spin loop (s_sleep) contains a load with the sc1 policy
+    before its backward branch -- the poll is not hoisted out of the loop."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    asm = str(tmp_path / "sweep.s")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                           "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
+                           "-I", os.path.join(ROOT, "include"), "-I", CSRC, "--cuda-device-only", "-S",
+                           os.path.join(CSRC, "stm_sgm_sweep.hip"), "-o", asm],
+                          stderr=subprocess.DEVNULL)
+    lines = open(asm).read().splitlines()
+    sleeps = [i for i, l in enumerate(lines) if re.match(r"\s*s_sleep\b", l)]
+    assert len(sleeps) >= 12, "expected the wait loops of six sweep kernels"
+    for i in sleeps:
+        body = []
+        for l in lines[i + 1:i + 80]:
+            body.append(l)
+            if re.match(r"\s*s_cbranch", l):
+                break
+        loads = [l for l in body if re.search(r"(buffer|global)_load_dword", l)]
+        assert loads and all(" sc1" in l for l in loads), "no sc1 poll in the loop at line %d:\n%s" % (
+            i + 1, "\n".join(body))
