@@ -194,13 +194,14 @@ def roofline(job, sgm_ms, traffic_and_note=(None, None)):
     traffic, note = traffic_and_note
     algorithmic = 8.0 * job.n_elems * job.batch  # read cost once + write sum once
     achieved = algorithmic / (sgm_ms * 1e-3) / 1e9
-    tiled = bool(getattr(job.sgm, "_last_tiled", False))
+    form = int(getattr(job.sgm, "_last_form", 0))  # 0 paired, 1 tiles behind row sweeps, 2 tiles behind walks
     tile = "sgm_tile_h2_kernel" if getattr(job, "D", 0) == 128 else "sgm_tile_kernel"
-    kernels = ("tiled form: sgm_hwalk_kernel + sgm_sweep_kernel (down, up) + " + tile if tiled
-               else "paired form: sgm_ckpt_kernel + 4 x sgm_pair_kernel")
+    kernels = {0: "paired form: sgm_ckpt_kernel + 4 x sgm_pair_kernel",
+               1: "tiled form: sgm_hwalk_kernel + sgm_sweep_kernel (down, up) + " + tile,
+               2: "tiled form behind walks: sgm_bwalk_kernel + " + tile}[form]
     return {"bound": "hbm", "traffic_note": note,
             "kernel": "semiglobal aggregation with fused WTA (stm_sgm_wta_f32), " + kernels,
-            "form": "tiled" if tiled else "paired",
+            "form": {0: "paired", 1: "tiled (sweeps)", 2: "tiled (walks)"}[form],
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes": algorithmic, "ms": round(sgm_ms, 4),

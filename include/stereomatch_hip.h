@@ -176,11 +176,24 @@ int stm_birchfield_ex_f32(const float *left, const float *right, float *cost,
 #define STM_SGM_PAIRED 64
 #define STM_SGM_TILED 128
 #define STM_SGM_COOPERATIVE 256
+/*   STM_SGM_WALKS   use the tiled form with its border states from per-path WALKS instead of row
+ *                   sweeps (one wave per path and direction reads the cost volume; seven or
+ *                   eight reads instead of three, but no serial hand-off per image row and no
+ *                   residency requirement: its status word is always 0).  What the library
+ *                   picks by itself for single pairs and small batches at D >= 128;
+ *                   STM_SGM_TILED means the sweep-fed variant wherever the device can hold it. */
+#define STM_SGM_WALKS 512
 size_t stm_sgm_workspace_bytes(int H, int W, int D, int batch, int flags);
 /* 1 when stm_sgm_f32 / stm_sgm_wta_f32 select the tiled form for this shape on the current
  * device, i.e. the workspace starts with the status word (a 256-byte header; also when such
  * a call then takes the paired form because of unaligned pointers), else 0. */
 int stm_sgm_uses_tiles(int H, int W, int D, int batch, int flags);
+/* Which form a call takes: STM_SGM_FORM_PAIRED, _SWEEPS (tiles behind row sweeps: the only one
+ * whose status word can ever be set) or _WALKS (tiles behind per-path walks). */
+#define STM_SGM_FORM_PAIRED 0
+#define STM_SGM_FORM_SWEEPS 1
+#define STM_SGM_FORM_WALKS 2
+int stm_sgm_form(int H, int W, int D, int batch, int flags);
 /* The status word's value given a HOST copy of the workspace's first 4 bytes (a helper for
  * bindings that cannot cast); 0 = ok. */
 #define STM_SGM_STATUS_TIMEOUT 1u

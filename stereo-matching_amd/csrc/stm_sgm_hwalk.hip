@@ -76,7 +76,7 @@ int tiled_launch_hwalk(const float *cost, const float *left, float *ws, const Ti
   const TiledGeom &G = c.G;
   HwalkArgs A;
   A.G = G; A.p1 = c.p1; A.p2 = c.p2; A.dlim = c.dlim;
-  A.only_left = G.D == 128;  // the D = 128 tile kernel carries the left-to-right states itself
+  A.only_left = c.by_rows;  // the D = 128 tile kernel then carries the left-to-right states itself
   const long waves = (A.only_left ? 1l : 2l) * G.H * G.batch;
   const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
   switch (G.D / 64) {

@@ -75,6 +75,8 @@ __global__ __launch_bounds__(2 * kT * 64, VPL >= 4 ? 4 : 8) void sgm_tile_kernel
       STM_STAMP_TILE_ID(id);
       STM_STAMP(0);
       const Entries<VPL, 0> E0now = E0;
+      // (the previous tile's winner-takes-all has read the sum tile: both groups are past B4)
+      if (P.accumulate) stage_accumulate_row<VPL>(St, out, G, x0, y0, tw, th, w, d0);
       STM_STAMP(1);
       lds_barrier();  // B0
       STM_STAMP(2);
@@ -167,6 +169,7 @@ int tiled_launch_tiles(const float *cost, const float *left, float *out, int32_t
   TileArgs A;
   A.G = G; A.p1 = c.p1; A.p2 = c.p2; A.dlim = c.dlim; A.true_paths = c.true_paths; A.accumulate = c.accumulate;
   A.stamps = c.tile_stamps;
+  A.by_rows = 0;
   // Persistent workgroups; tiles are dealt round robin.  D = 256: one sixteen-wave workgroup per
   // CU (the LDS allows no more); D = 64: two.
   const long long ntiles = (long long)G.nTR * G.nTC * G.batch;

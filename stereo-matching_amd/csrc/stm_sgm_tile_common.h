@@ -32,6 +32,7 @@ struct TileArgs {
   int dlim;
   int true_paths;
   int accumulate;  // STM_SGM_ACCUMULATE: the sum starts from the caller's contents of `out`, not from 0
+  int by_rows;     // D = 128 kernel: workgroups own whole tile rows and carry the rightward state along them
   unsigned long long *stamps;  // diagnostic builds only (stm_sgm_tiled_diag.h), else null
 };
 
@@ -147,6 +148,20 @@ __device__ __forceinline__ void tile_wta_lds(const float *St, int wave, int lane
   if (r == 0 && px < tw && py < th) disp[tile_out_pixel(G, x0, y0, pix)] = k;
 }
 
+// STM_SGM_ACCUMULATE: tile row `r` of the caller's `out` goes into the sum tile before the tile's
+// first update (which then starts from it instead of from 0).  A compatibility path (the
+// reference's `+=` into a pre-filled tensor): its loads are not prefetched.
+template <int VPL>
+__device__ __forceinline__ void stage_accumulate_row(float *St, const float *__restrict__ out, const TiledGeom &G,
+                                                     int x0, int y0, int tw, int th, int r, int d0) {
+  constexpr int D = 64 * VPL;
+  if (r >= th) return;
+  for (int c = 0; c < tw; ++c) {
+    const Row<VPL> v = load_row<VPL, true>(out, (size_t)tile_out_pixel(G, x0, y0, r * kT + c), D, d0);
+    store_row<VPL, true>(St + (size_t)(r * kT + c) * st_stride(D), 0, D, d0, v);
+  }
+}
+
 // The slots of a wave's phase: pixel index (y * 8 + x, tile coordinates) of every slot.
 template <int PHASE>
 struct Slots {
@@ -249,14 +264,10 @@ __device__ __forceinline__ void tile_add(const PhaseGeom &g, const Slots<PHASE> 
     if (s < nT) {
       const int pix = sl.pix[s];
       Row<VPL> acc;
-      if (PHASE == 0) {
-        if (P.accumulate) {
-          acc = load_row<VPL, true>(out, (size_t)tile_out_pixel(P.G, x0, y0, pix), D, d0);
-        } else {
+      if (PHASE == 0 && !P.accumulate) {
 #pragma unroll
-          for (int j = 0; j < VPL; ++j) acc.v[j] = 0.0f;
-        }
-      } else {
+        for (int j = 0; j < VPL; ++j) acc.v[j] = 0.0f;
+      } else {  // (STM_SGM_ACCUMULATE: the tile's staging has put the caller's `out` into the sum tile)
         acc = lds_srow<VPL>(St, pix, d0);
       }
       if (PHASE == 2) {
@@ -351,17 +362,18 @@ __device__ __forceinline__ void tile_chains_fast(const Slots<PHASE> &sl, const E
 // ... and the sum update when every direction counts once: S = (S + F) + I.
 template <int VPL, int PHASE, int FINAL>
 __device__ __forceinline__ void tile_add_fast(const Slots<PHASE> &sl, const Row<VPL> (&LF)[kT],
-                                              const Row<VPL> (&LI)[kT], bool inv_a, bool inv_b, float *St, const TiledGeom &G, int x0, int y0,
+                                              const Row<VPL> (&LI)[kT], bool inv_a, bool inv_b, float *St, const TiledGeom &G, bool accumulate, int x0, int y0,
                                               float *__restrict__ out, int32_t *__restrict__ disp, int lane) {
   constexpr int D = 64 * VPL;
   const int d0 = lane * VPL;
+  const bool from_tile = PHASE != 0 || accumulate;  // (accumulating: pair 0 starts from the staged `out`)
   Row<VPL> sn;
-  if (PHASE != 0) sn = lds_srow<VPL>(St, sl.pix[0], d0);
+  if (from_tile) sn = lds_srow<VPL>(St, sl.pix[0], d0);
 #pragma unroll
   for (int s = 0; s < kT; ++s) {
     const int pix = sl.pix[s];
     Row<VPL> acc;
-    if (PHASE == 0) {
+    if (!from_tile) {
 #pragma unroll
       for (int j = 0; j < VPL; ++j) acc.v[j] = 0.0f;
     } else {
@@ -397,7 +409,7 @@ __device__ __forceinline__ void tile_pair(const PhaseGeom &g, const Entries<VPL,
   // (the reference skips the inverse diagonals of 17-44 % of a wide image's pixels, Q6: those
   // segments' I chains are not even computed); what is left for the generic forms are the
   // tiles on the image border and on the re-walked corner diagonals.
-  bool fast = full && E.start == 0 && !(PHASE == 0 && P.accumulate);  // (accumulating: pair 0 starts from `out`, tile_add)
+  bool fast = full && E.start == 0;
   bool inv_a = true, inv_b = true;
   if (PHASE >= 2 && fast) {
     const Counts ca = seg_counts(PHASE, g.a, x0, y0, P.G, P.true_paths);
@@ -409,7 +421,7 @@ __device__ __forceinline__ void tile_pair(const PhaseGeom &g, const Entries<VPL,
   if (fast) {
     tile_chains_fast<VPL, PHASE>(sl, E, inv_a, inv_b, Ct, Ip, P.p1, P.p2, X, lane, LF, LI);
     between();
-    tile_add_fast<VPL, PHASE, FINAL>(sl, LF, LI, inv_a, inv_b, St, P.G, x0, y0, out, disp, lane);
+    tile_add_fast<VPL, PHASE, FINAL>(sl, LF, LI, inv_a, inv_b, St, P.G, P.accumulate != 0, x0, y0, out, disp, lane);
   } else {
     tile_chains<VPL, PHASE>(sl, E, Ct, Ip, P.p1, P.p2, X, lane, LF, LI);
     between();

@@ -134,14 +134,9 @@ __device__ __forceinline__ void h2_pair(const H2Pair &K, const Row<4> (&E)[4], i
   // (pair 0: nothing to read).  Pair 3 leaves the result in `acc` for `finish2`.
   auto update = [&](auto s_, Row<4> &acc) {
     constexpr int s = decltype(s_)::value;
-    if (PHASE == 0) {
-      if (accumulate) {  // STM_SGM_ACCUMULATE: the sum starts from the caller's contents of `out`
-        const int p = s < NA ? K.pix0 + s * pstep : K.pix1 + (s - NA) * pstep;
-        acc = load_row<4, true>(out, (size_t)tile_out_pixel(G, x0, y0, p), 128, hl16 >> 2);
-      } else {
+    if (PHASE == 0 && !accumulate) {  // (accumulating: `acc` is the staged `out`, read like any other pair's sum)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc.v[j] = 0.0f;
-      }
+      for (int j = 0; j < 4; ++j) acc.v[j] = 0.0f;
     }
     f32x2 lo = f32x2{acc.v[0], acc.v[1]}, hi = f32x2{acc.v[2], acc.v[3]};
     const f32x2 ilo = f32x2{LI[s].v[0], LI[s].v[1]}, ihi = f32x2{LI[s].v[2], LI[s].v[3]};
@@ -192,7 +187,7 @@ __device__ __forceinline__ void h2_pair(const H2Pair &K, const Row<4> (&E)[4], i
   };
   auto sum_of = [&](auto s_) {
     Row<4> r;
-    if (PHASE != 0) r = h2_lds_row(St, saddr(s_));
+    if (PHASE != 0 || accumulate) r = h2_lds_row(St, saddr(s_));
     else r = E[0];  // (unused: any defined value)
     return r;
   };
@@ -371,14 +366,18 @@ __global__ __launch_bounds__(4 * 64, 2) void sgm_tile_h2_kernel(const float *__r
   // two tiles of this form; otherwise it goes through the column border states, which every
   // tile writes) -- there is no left-to-right horizontal walk at D = 128, i.e. one read of the
   // cost volume fewer.
-  const int nrows = G.batch * G.nTR;
-  TileRowWalk cur_t, next_t;  // the tile being computed / the one being prefetched
-  cur_t.init((int)blockIdx.x, G);
-  if (cur_t.row >= nrows) return;
+  // ... when the call's border states come from row sweeps (P.by_rows); behind border walks
+  // (single pairs, small batches) every direction's states are there and the workgroups take
+  // single tiles, round robin: a pair has 47 tile rows for 512 workgroups.
+  const bool by_rows = P.by_rows != 0;
+  const int nunits = TileUnitWalk::units(G, by_rows);
+  TileUnitWalk cur_t, next_t;  // the tile being computed / the one being prefetched
+  cur_t.init((int)blockIdx.x, G, by_rows);
+  if (cur_t.unit >= nunits) return;
   next_t = cur_t;
 
   // A tile is interior when all of its neighbours exist (every line enters from a border state).
-  auto interior = [&](const TileRowWalk &t) { return tile_interior(G, t.trow, t.tcol); };
+  auto interior = [&](const TileUnitWalk &t) { return tile_interior(G, t.trow, t.tcol); };
   Row<4> cpre[kT];  // next tile: tile row 2 w + half of the cost tile
   float ipre = 0.0f;
   Row<4> E0[4], E1[4];  // next tile: entry states of pairs 0 and 1 (interior tiles)
@@ -387,7 +386,7 @@ __global__ __launch_bounds__(4 * 64, 2) void sgm_tile_h2_kernel(const float *__r
   // Every prefetch redefines all of its registers unconditionally (past the last tile it
   // re-reads that tile; rows and samples outside a partial tile are clamped into it; the
   // entry states of a tile that is not interior are read at the workspace's first border row).
-  auto prefetch_cost = [&](const TileRowWalk &t) {
+  auto prefetch_cost = [&](const TileUnitWalk &t) {
     const int x0 = t.tcol * kT, y0 = t.trow * kT;
     const int tw = imin(kT, G.W - x0), th = imin(kT, G.H - y0);
     const float *cost = cost_all + (size_t)t.b * npix * D;
@@ -398,7 +397,7 @@ __global__ __launch_bounds__(4 * 64, 2) void sgm_tile_h2_kernel(const float *__r
     ipre = image_all[(size_t)t.b * npix +
                      tile_intensity_pixel(G, x0, y0, imin((int)threadIdx.x, (kT + 2) * (kT + 2) - 1))];
   };
-  auto entry_base = [&](const TileRowWalk &t) {
+  auto entry_base = [&](const TileUnitWalk &t) {
     H2TileBase T = h2_tile_base(ws, G, t);
     if (!interior(t)) {  // a valid dummy address: the first border row of the workspace
       T.row = ws + G.rowb_off;
@@ -415,7 +414,7 @@ __global__ __launch_bounds__(4 * 64, 2) void sgm_tile_h2_kernel(const float *__r
     const int tw = imin(kT, G.W - x0), th = imin(kT, G.H - y0);
     float *out = out_all ? out_all + (size_t)b * npix * D : nullptr;
     int32_t *disp = disp_all ? disp_all + (size_t)b * npix : nullptr;
-    STM_STAMP_TILE_ID(cur_t.row * G.nTC + cur_t.tcol);
+    STM_STAMP_TILE_ID((cur_t.b * G.nTR + cur_t.trow) * G.nTC + cur_t.tcol);
     STM_STAMP_WAVE_ID(w);
     STM_STAMP(0);
     const int cls2 = h2_count_class(2, G, x0, y0, P.true_paths), cls3 = h2_count_class(3, G, x0, y0, P.true_paths);
@@ -425,6 +424,13 @@ __global__ __launch_bounds__(4 * 64, 2) void sgm_tile_h2_kernel(const float *__r
       for (int c = 0; c < kT; ++c) h2_lds_store(Ct, ((2 * w + half) * kT + c) * D * 4 + hl16, cpre[c]);
     }
     if (threadIdx.x < (kT + 2) * (kT + 2)) Ip[threadIdx.x] = ipre;
+    // (STM_SGM_ACCUMULATE: the caller's `out` becomes the sum tile's start.  A wave stages the
+    // tile rows 2 w and 2 w + 1 -- the sixteen pixels whose winner it took from the previous tile's
+    // sum, the sum tile's last reader, earlier in its own program.)
+    if (P.accumulate) {
+      stage_accumulate_row<2>(St, out, G, x0, y0, tw, th, 2 * w, lane * 2);
+      stage_accumulate_row<2>(St, out, G, x0, y0, tw, th, 2 * w + 1, lane * 2);
+    }
     Row<4> Ea[4], Eb[4];
     Ea[0] = pick_row(have_carry, carry, E0[0]);
     Ea[1] = E0[1];
@@ -434,22 +440,21 @@ __global__ __launch_bounds__(4 * 64, 2) void sgm_tile_h2_kernel(const float *__r
     STM_STAMP(2);
     bool more;
     {
-      TileRowWalk n = cur_t;
-      n.next(G, stride);
-      more = n.row < nrows;
+      TileUnitWalk n = cur_t;
+      n.next(G, stride, by_rows);
+      more = n.unit < nunits;
       if (more) next_t = n;
     }
     // Where the rows of this tile leave it to the right (column border states of direction 0).
     float *exits = colb_ptr(ws, G, b, 0, cur_t.tcol, y0);
     // A global load takes several times as long as a pair (2-4 us against ~1 us), and results
-    // return in issue order: the entry states of pairs 2 and 3 are requested now, then the next
-    // tile's cost rows; the next tile's pairs 0 and 1 follow once pairs 0 and 1 are done.
+    // return in issue order: the entry states of pairs 2 and 3 are requested now; the next tile's
+    // cost rows and its pairs 0 and 1 follow once pairs 0 and 1 are done.
     if (fast) {
       const H2TileBase T = h2_tile_base(ws, G, cur_t);
       Row<4> Ec[4], Ed[4], unused;
       h2_load_entries<4>(Ec, K2, T, d0);
       h2_load_entries<4>(Ed, K3, T, d0);
-      prefetch_cost(next_t);
       // The penalties of all four pairs now: four independent division sequences instead of one
       // in front of every pair's chains.
       const int na = h2_na(2, w);
@@ -458,10 +463,15 @@ __global__ __launch_bounds__(4 * 64, 2) void sgm_tile_h2_kernel(const float *__r
       const float pen2 = h2_penalties<2>(K2, na, Ip, P.p1, P.p2, lane);
       const float pen3 = h2_penalties<3>(K3, na, Ip, P.p1, P.p2, lane);
       h2_pair_w<0, FINAL>(w, half, K0, Ea, 1, P, Ct, St, pen0, X, lane, hl16, x0, y0, out, disp, carry, [] {});
-      have_carry = true;
-      store_row<4, true>(exits + (size_t)(2 * w + half) * D, 0, D, d0, carry);
+      have_carry = by_rows;
+      if (by_rows) store_row<4, true>(exits + (size_t)(2 * w + half) * D, 0, D, d0, carry);
       h2_pair_w<1, FINAL>(w, half, K1, Eb, 1, P, Ct, St, pen1, X, lane, hl16, x0, y0, out, disp, unused,
                           [] { lds_barrier(); });
+      // (the next tile's cost rows: 32 registers that pairs 0 and 1, with the entry states of all
+      // four pairs live, do not have; two pairs are still ahead to cover the loads.  Measured
+      // against requesting them at the start of the tile: 42.1 / 42.6 against 42.3 / 43.4 ms per
+      // 256 Teddy pairs, fused / unfused)
+      prefetch_cost(next_t);
       h2_load_entries<2>(E0, K0, entry_base(next_t), d0);
       h2_load_entries<2>(E1, K1, entry_base(next_t), d0);
       h2_pair_w<2, FINAL>(w, half, K2, Ec, cls2, P, Ct, St, pen2, X, lane, hl16, x0, y0, out, disp, unused,
@@ -485,7 +495,7 @@ __global__ __launch_bounds__(4 * 64, 2) void sgm_tile_h2_kernel(const float *__r
       h2_generic_entries<2>(Q2, w, tw, th, P, B, x0, y0, lane);
       h2_generic_entries<3>(Q3, w, tw, th, P, B, x0, y0, lane);
       prefetch_cost(next_t);
-      h2_pair_generic<0, FINAL>(Q0, w, tw, th, Ct, St, Ip, P, x0, y0, out, disp, X1, lane, exits, [] {});
+      h2_pair_generic<0, FINAL>(Q0, w, tw, th, Ct, St, Ip, P, x0, y0, out, disp, X1, lane, by_rows ? exits : nullptr, [] {});
       h2_pair_generic<1, FINAL>(Q1, w, tw, th, Ct, St, Ip, P, x0, y0, out, disp, X1, lane, nullptr,
                                 [] { lds_barrier(); });
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... and this tile's for the next one
@@ -515,9 +525,10 @@ int tiled_launch_tiles_h2(const float *cost, const float *left, float *out, int3
   TileArgs A;
   A.G = G; A.p1 = c.p1; A.p2 = c.p2; A.dlim = c.dlim; A.true_paths = c.true_paths; A.accumulate = c.accumulate;
   A.stamps = c.tile_stamps;
-  // Four-wave workgroups, two per CU, each owning whole tile rows.
-  const long long wgs = (long long)c.cus * 2, rows = (long long)G.nTR * G.batch;
-  const dim3 grid((unsigned)(rows < wgs ? rows : wgs)), block(4 * 64);
+  A.by_rows = c.by_rows ? 1 : 0;
+  // Four-wave workgroups, two per CU, each owning whole tile rows (or single tiles).
+  const long long wgs = (long long)c.cus * 2, units = TileUnitWalk::units(G, c.by_rows);
+  const dim3 grid((unsigned)(units < wgs ? units : wgs)), block(4 * 64);
   if (final_mode == 0)
     hipLaunchKernelGGL((sgm_tile_h2_kernel<0>), grid, block, 0, s, cost, left, out, disp, ws, A);
   else if (final_mode == 1)

@@ -6,10 +6,16 @@
 
 namespace stm {
 
-// Whether the tiled form covers this call (shape, flags, device) and is expected to be the
-// faster one.  Deterministic in its arguments and the current device, so that
-// stm_sgm_workspace_bytes() and stm_sgm_f32() always agree.
-bool sgm_tiled_selected(int H, int W, int D, int batch, int flags);
+// Which form the aggregation takes for this call (shape, flags, device): the paired form
+// (stm_sgm.hip), or the tiled form with its border states from row sweeps (large batches; the
+// workspace's status word can be set) or from per-path walks (single pairs and small batches;
+// no waits, the status word stays 0).  Deterministic in its arguments and the current device, so
+// that stm_sgm_workspace_bytes() and stm_sgm_f32() always agree.
+enum SgmForm { kSgmPaired = 0, kSgmTiledSweeps = 1, kSgmTiledWalks = 2 };
+SgmForm sgm_form(int H, int W, int D, int batch, int flags);
+inline bool sgm_tiled_selected(int H, int W, int D, int batch, int flags) {
+  return sgm_form(H, W, D, batch, flags) != kSgmPaired;
+}
 
 // The tiled form moves whole 16-byte lanes: cost, out and workspace must be 16-byte aligned
 // (a call that is not, and does not force STM_SGM_TILED, takes the paired form instead).
@@ -23,6 +29,7 @@ constexpr size_t kSgmWorkspaceHeader = 256;
 size_t sgm_tiled_workspace_bytes(int H, int W, int D, int batch, int flags);
 
 // final_mode as in sgm_run (stm_sgm.hip): 0 sum only, 1 sum + disparity, 2 disparity only.
+// Runs whichever tiled variant sgm_form() names for the call.
 int sgm_run_tiled(const float *cost, const float *left, float *out, int32_t *disp, int H, int W,
                   int D, float penalty1, float penalty2, int flags, void *workspace,
                   size_t workspace_bytes, int batch, hipStream_t stream, int final_mode);

@@ -107,21 +107,36 @@ bool shape_ok(int H, int W, int D, int batch, int flags) {
 
 }  // namespace
 
-bool sgm_tiled_selected(int H, int W, int D, int batch, int flags) {
-  if (!shape_ok(H, W, D, batch, flags)) return false;
+SgmForm sgm_form(int H, int W, int D, int batch, int flags) {
+  if (!shape_ok(H, W, D, batch, flags)) return kSgmPaired;
+  TiledGeom G;
+  long long total = 0, zero = 0;
+  if (!make_geom(H, W, D, batch, G, total, zero)) return kSgmPaired;
+  // The walk-fed variant needs nothing of the device; the sweep-fed one needs its strips on
+  // distinct CUs (make_plan) and a sweep workgroup that fits one (tiled_sweep_fits).
   TiledPlan plan;
-  if (!make_plan(H, W, D, batch, plan)) return false;
-  if (!tiled_sweep_fits(D)) return false;
-  if (flags & STM_SGM_TILED) return true;
-  // Measured on MI355X (tools/sgm_forms.py): the tiled form wins where the volume traffic it
-  // saves outweighs its fixed costs per image row and per tile, i.e. for wide disparity ranges
-  // with enough columns in the batch to keep the row sweeps' column strips on most CUs:
-  // D = 256: from 2 pairs at 1080p (10.8 against 11.3 ms for two, 4.5 against 5.7 ms per pair for
-  // three, 4.0 against 5.8 at 8-16; 8.0 against 5.9 ms for a single pair); D = 128: from ~28 Teddy
-  // pairs (5.6 against 5.3 ms at 24, 6.2 against 7.2 at 32, 42 against 55 at 256); D = 64: the paired
-  // form is 1.4x faster and keeps the job.
-  const long long need = (long long)plan.cus * sweep_strip_cols(D / 64) * (D == 256 ? 9 : 15);  // tenths
-  return D >= 128 && (long long)batch * W * 2 * 10 >= need && H >= 64;
+  const bool sweeps_ok = make_plan(H, W, D, batch, plan) && tiled_sweep_fits(D);
+  if (flags & STM_SGM_WALKS) return kSgmTiledWalks;
+  if (flags & STM_SGM_TILED) return sweeps_ok ? kSgmTiledSweeps : kSgmTiledWalks;
+  if (D < 128) return kSgmPaired;  // D = 64: the paired form is 1.4x faster than either
+  // Measured on MI355X (tools/sgm_forms.py, fused, ms per pair):
+  //   Teddy 375 x 450, D = 128     B = 1     2     4     16    24    32    256
+  //     paired                     0.570 0.346 0.263 0.236 0.229 0.230 0.215
+  //     tiles behind walks         0.307 0.227 0.234 0.229 0.228 0.227
+  //     tiles behind sweeps        3.53        0.93  0.29  0.23  0.19  0.162
+  //   1080p, D = 256               B = 1     2     3     8
+  //     paired                     5.89  5.98  5.75  5.63
+  //     tiles behind walks         5.25  5.22  5.00
+  //     tiles behind sweeps        7.96  5.34  4.5   4.0
+  // (240 x 320 x 128: 0.196 against 0.379; 96 x 128 x 128: 0.081 against 0.170; 64 x 64 x 256: 0.046
+  // against 0.120 for one pair.)  A sweep costs its image rows x ~3 us whatever the batch, so the
+  // sweep-fed form needs enough columns in the batch to keep its column strips on most CUs;
+  // below that the walk-fed tiles are never behind the paired form.
+  if (sweeps_ok && H >= 64) {
+    const long long need = (long long)plan.cus * sweep_strip_cols(D / 64) * (D == 256 ? 12 : 15);  // tenths
+    if ((long long)batch * W * 2 * 10 >= need) return kSgmTiledSweeps;
+  }
+  return (H >= 16 && W >= 16) ? kSgmTiledWalks : kSgmPaired;
 }
 
 bool sgm_tiled_aligned(const void *cost, const void *out, const void *workspace, int final_mode) {
@@ -131,18 +146,31 @@ bool sgm_tiled_aligned(const void *cost, const void *out, const void *workspace,
 }
 
 size_t sgm_tiled_workspace_bytes(int H, int W, int D, int batch, int flags) {
-  if (!sgm_tiled_selected(H, W, D, batch, flags)) return 0;
-  TiledPlan plan;
-  make_plan(H, W, D, batch, plan);
-  return plan.total_floats * sizeof(float);
+  if (sgm_form(H, W, D, batch, flags) == kSgmPaired) return 0;
+  TiledGeom G;
+  long long total = 0, zero = 0;
+  make_geom(H, W, D, batch, G, total, zero);
+  return (size_t)total * sizeof(float);
 }
 
 int sgm_run_tiled(const float *cost, const float *left, float *out, int32_t *disp, int H, int W,
                   int D, float penalty1, float penalty2, int flags, void *workspace,
                   size_t workspace_bytes, int batch, hipStream_t stream, int final_mode) {
+  const SgmForm form = sgm_form(H, W, D, batch, flags);
+  STM_REQUIRE(form != kSgmPaired, STM_EUNSUPPORTED, "stm_sgm_f32: the tiled form does not cover this call");
   TiledPlan plan;
-  STM_REQUIRE(shape_ok(H, W, D, batch, flags) && make_plan(H, W, D, batch, plan), STM_EUNSUPPORTED,
-              "stm_sgm_f32: the tiled form does not cover this call");
+  if (form == kSgmTiledSweeps) {
+    make_plan(H, W, D, batch, plan);
+  } else {
+    long long total = 0, zero = 0;
+    make_geom(H, W, D, batch, plan.G, total, zero);
+    plan.total_floats = (size_t)total;
+    plan.zero_bytes = 0;  // (no mailboxes; the walk kernel clears the status word itself)
+    plan.status_off = 0;
+    plan.group = 0;
+    plan.cus = device_cus();
+    STM_REQUIRE(plan.cus > 0, STM_EHIP, "stm_sgm_f32: no HIP device");
+  }
   const size_t need = plan.total_floats * sizeof(float);
   STM_REQUIRE(workspace && workspace_bytes >= need, STM_EWORKSPACE,
               "stm_sgm_f32: needs a workspace of %zu bytes (stm_sgm_workspace_bytes)", need);
@@ -156,6 +184,7 @@ int sgm_run_tiled(const float *cost, const float *left, float *out, int32_t *dis
   c.true_paths = (flags & STM_SGM_TRUE_PATHS) ? 1 : 0;
   c.accumulate = (flags & STM_SGM_ACCUMULATE) ? 1 : 0;
   c.cooperative = (flags & STM_SGM_COOPERATIVE) != 0 || getenv("STM_SWEEP_COOPERATIVE") != nullptr;
+  c.by_rows = form == kSgmTiledSweeps && D == 128;
   c.status_off = plan.status_off;
   c.group = plan.group;
   c.cus = plan.cus;
@@ -169,12 +198,16 @@ int sgm_run_tiled(const float *cost, const float *left, float *out, int32_t *dis
   constexpr int skip = 0;
 #endif
   float *ws = static_cast<float *>(workspace);
-  if (hipMemsetAsync(ws, 0, plan.zero_bytes, stream) != hipSuccess)
+  if (plan.zero_bytes && hipMemsetAsync(ws, 0, plan.zero_bytes, stream) != hipSuccess)
     return fail(STM_EHIP, "stm_sgm_f32 (tiled): hipMemsetAsync failed");
   int rc = STM_OK;
-  if (!(skip & 1)) rc = tiled_launch_hwalk(cost, left, ws, c, stream);
-  for (int up = 0; up < 2 && rc == STM_OK && !(skip & 2); ++up)
-    rc = tiled_launch_sweep(cost, left, ws, c, up != 0, stream);
+  if (form == kSgmTiledWalks) {
+    if (!(skip & 3)) rc = tiled_launch_bwalk(cost, left, ws, c, stream);
+  } else {
+    if (!(skip & 1)) rc = tiled_launch_hwalk(cost, left, ws, c, stream);
+    for (int up = 0; up < 2 && rc == STM_OK && !(skip & 2); ++up)
+      rc = tiled_launch_sweep(cost, left, ws, c, up != 0, stream);
+  }
   if (rc != STM_OK || (skip & 4)) return rc;
   return D == 128 ? tiled_launch_tiles_h2(cost, left, out, disp, ws, c, final_mode, stream)
                   : tiled_launch_tiles(cost, left, out, disp, ws, c, final_mode, stream);

@@ -192,6 +192,96 @@ STM_HD int hwalk_col(int W, bool leftward, int i) {
   return leftward ? W - 1 - j : j;
 }
 
+// ---- border walks (the sweep-free way to the border states) -----------------------------------
+// One wave walks one TRUE path of one of the eight directions (every pixel lies on exactly one
+// path per direction; the reference's quirks for the inverse diagonals are the tile kernel's
+// business, which simply does not use what the reference never runs) and stores its state where
+// the path leaves a tile.  Lines of an image, in this order (long ones first):
+//   direction 0 (right) and 1 (left): H rows each; 2 (down), 3 (up): W columns each;
+//   4 (down-right), 5 (up-left): the W + H - 1 diagonals x - y = c, c = -(H - 1) .. W - 1;
+//   6 (down-left), 7 (up-right): the W + H - 1 anti-diagonals x + y = s, s = 0 .. W + H - 2.
+// skip_right (D = 128): direction 0 is left out (that tile kernel carries it along its tile rows).
+struct WalkLine {
+  int dir, index;  // direction and the line's number within it
+  int x0, y0, dx, dy, len;
+};
+STM_HD int bwalk_lines_of_dir(const TiledGeom &G, int dir) {
+  return dir < 2 ? G.H : (dir < 4 ? G.W : G.W + G.H - 1);
+}
+STM_HD int bwalk_lines(const TiledGeom &G, bool skip_right) {
+  return (skip_right ? 1 : 2) * G.H + 2 * G.W + 4 * (G.W + G.H - 1);
+}
+STM_HD WalkLine bwalk_line(const TiledGeom &G, bool skip_right, int l) {
+  WalkLine k;
+  int dir = skip_right ? 1 : 0;
+  while (l >= bwalk_lines_of_dir(G, dir)) {
+    l -= bwalk_lines_of_dir(G, dir);
+    ++dir;
+  }
+  k.dir = dir;
+  k.index = l;
+  const int W = G.W, H = G.H;
+  int sx, sy, n;  // first pixel and length of the line in its forward direction (0, 2, 4, 6)
+  int fdx, fdy;
+  if (dir < 2) { sx = 0; sy = l; n = W; fdx = 1; fdy = 0; }
+  else if (dir < 4) { sx = l; sy = 0; n = H; fdx = 0; fdy = 1; }
+  else if (dir < 6) {
+    const int c = l - (H - 1);
+    sx = c > 0 ? c : 0; sy = c > 0 ? 0 : -c;
+    n = imin_(W - sx, H - sy); fdx = 1; fdy = 1;
+  } else {
+    const int sum = l;
+    sx = imin_(sum, W - 1); sy = sum - sx;
+    n = imin_(sx + 1, H - sy); fdx = -1; fdy = 1;
+  }
+  if (dir & 1) {  // the inverse direction starts at the line's far end
+    k.x0 = sx + (n - 1) * fdx; k.y0 = sy + (n - 1) * fdy; k.dx = -fdx; k.dy = -fdy;
+  } else {
+    k.x0 = sx; k.y0 = sy; k.dx = fdx; k.dy = fdy;
+  }
+  k.len = n;
+  return k;
+}
+// Lines nobody reads: the reference never runs the inverse passes of some diagonals (SURVEY A.3
+// Q6; seg_counts gives them inv = 0 and the tile kernels do not compute those chains), so their
+// walks are left out -- on a 1920 x 1080 image 840 of the 2999 up-left and of the up-right lines,
+// the full-length ones: 44 % of the pixels of either direction.  `c` / `sum`: the line's x - y /
+// x + y.  Nothing is skipped with true_paths.
+STM_HD bool bwalk_line_used(const TiledGeom &G, int dir, int l, int true_paths) {
+  if (true_paths) return true;
+  const int e = G.W - G.H;
+  if (dir == 5) {
+    const int c = l - (G.H - 1);
+    if (e > 0) return !(c >= 0 && c < e);
+    if (e < -1) return !(c > e && c < 0);
+    return true;
+  }
+  if (dir == 7 && e > 0) return !(l >= G.H && l <= G.W - 1);
+  return true;
+}
+// Pixel index (inside the image) of step i of a line; prefetches past its end re-read the last.
+STM_HD unsigned bwalk_pixel(const TiledGeom &G, const WalkLine &k, int i) {
+  const int j = imin_(i, k.len - 1);
+  return (unsigned)(k.y0 * G.W + k.x0 + j * (k.dy * G.W + k.dx));
+}
+// Where direction `dir` keeps its state: on row lines (y % 8 == rv, block index rk) and / or
+// column lines (x % 8 == cv, block index ck); -1: none.  = what border_in_image reads.
+struct WalkStores {
+  int rk, rv, ck, cv;
+};
+STM_HD WalkStores bwalk_stores(int dir) {
+  switch (dir) {
+    case 0: return {-1, 0, 0, 7};
+    case 1: return {-1, 0, 3, 0};
+    case 2: return {0, 7, -1, 0};
+    case 3: return {3, 0, -1, 0};
+    case 4: return {1, 7, 1, 7};
+    case 5: return {5, 0, 5, 0};
+    case 6: return {2, 7, 4, 0};
+    default: return {4, 0, 2, 7};
+  }
+}
+
 // ---- tiles ----------------------------------------------------------------------------------------
 struct Seg {
   int ex, ey, n;  // first pixel in F order (tile coordinates) and pixel count
@@ -301,6 +391,34 @@ struct TileRowWalk {
   }
   STM_HD void next(const TiledGeom &G, int stride) {
     if (++tcol == G.nTC) init(row + stride, G);
+  }
+};
+// ... or either, chosen at run time (the D = 128 tile kernel: whole tile rows when it carries the
+// left-to-right state along them, single tiles when that state comes from a walk -- a single
+// pair has 47 tile rows for 512 workgroups).  `unit` counts rows or tiles.
+struct TileUnitWalk {
+  int b, trow, tcol, unit;
+  STM_HD static int units(const TiledGeom &G, bool by_rows) { return G.batch * G.nTR * (by_rows ? 1 : G.nTC); }
+  STM_HD void init(int u, const TiledGeom &G, bool by_rows) {
+    unit = u;
+    if (by_rows) {
+      b = u / G.nTR;
+      trow = u - b * G.nTR;
+      tcol = 0;
+    } else {
+      const int per_image = G.nTR * G.nTC;
+      b = u / per_image;
+      const int t = u - b * per_image;
+      trow = t / G.nTC;
+      tcol = t - trow * G.nTC;
+    }
+  }
+  STM_HD void next(const TiledGeom &G, int stride, bool by_rows) {
+    if (by_rows) {
+      if (++tcol == G.nTC) init(unit + stride, G, true);
+    } else {
+      init(unit + stride, G, false);
+    }
   }
 };
 // A tile all of whose neighbours exist (every line enters from a border state).

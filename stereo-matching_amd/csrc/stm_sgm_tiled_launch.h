@@ -15,6 +15,8 @@ struct TiledCall {
   int true_paths;     // STM_SGM_TRUE_PATHS
   int accumulate;     // STM_SGM_ACCUMULATE
   bool cooperative;   // STM_SGM_COOPERATIVE
+  bool by_rows;       // D = 128 behind sweeps: the tile kernel owns tile rows and carries the
+                      // left-to-right state itself (no walk of that direction)
   long long status_off;
   int group;          // images per sweep launch
   int cus;
@@ -23,6 +25,9 @@ struct TiledCall {
 
 // stm_sgm_hwalk.hip: the horizontal walks (both directions; D = 128: right-to-left only).
 int tiled_launch_hwalk(const float *cost, const float *left, float *ws, const TiledCall &c, hipStream_t s);
+// stm_sgm_bwalk.hip: the border states of all eight directions (seven at D = 128) by walks, in
+// place of the horizontal walks and the two sweeps.
+int tiled_launch_bwalk(const float *cost, const float *left, float *ws, const TiledCall &c, hipStream_t s);
 // stm_sgm_sweep.hip: the down (up = false) or up row sweep over the whole batch.
 int tiled_launch_sweep(const float *cost, const float *left, float *ws, const TiledCall &c, bool up, hipStream_t s);
 // Whether one sweep workgroup fits a CU of the current device at this D (asked once per device).

@@ -22,8 +22,9 @@ STM_SGM_KEEP_SUM = 4
 STM_SGM_FULL_MIN = 8
 STM_SGM_TRUE_PATHS = 16
 STM_SGM_EXACT_NONFINITE = 32
-STM_SGM_FORMS = {"auto": 0, "paired": 64, "tiled": 128}
+STM_SGM_FORMS = {"auto": 0, "paired": 64, "tiled": 128, "walks": 512}
 STM_SGM_COOPERATIVE = 256
+STM_SGM_FORM_PAIRED, STM_SGM_FORM_SWEEPS, STM_SGM_FORM_WALKS = 0, 1, 2
 STM_DP_MODES = {"reference": 0, "corrected": 1}
 STM_BT_INDEXING = {"reference": 0, "padded": 1}
 
@@ -39,6 +40,7 @@ PROTOTYPES = {
     "stm_sgm_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "stm_sgm_status": (ctypes.c_uint, [_vp]),
     "stm_sgm_uses_tiles": (_i, [_i, _i, _i, _i, _i]),
+    "stm_sgm_form": (_i, [_i, _i, _i, _i, _i]),
     "stm_sgm_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _sz, _i, _vp]),
     "stm_sgm_wta_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _sz, _i, _vp]),
     "stm_wta_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

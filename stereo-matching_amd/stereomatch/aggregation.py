@@ -43,8 +43,9 @@ class Semiglobal:
         self.full_min = full_min
         self.exact_nonfinite = exact_nonfinite
         # "auto": the library picks per call between its paired form (a wave per path) and its
-        # tiled form (row sweeps + 8x8 tiles; large batches of D = 64/128/256 volumes);
-        # "paired" / "tiled" force one (tiled only where it covers the call).  Same bits.
+        # tiled form (8x8 tiles rebuilt from border states, D = 64/128/256), the latter fed by row
+        # sweeps (large batches) or by per-path walks (single pairs, small batches);
+        # "paired" / "tiled" / "walks" force one (where it covers the call).  Same bits.
         if form not in _native.STM_SGM_FORMS:
             raise ValueError("Semiglobal form must be one of %s" % sorted(_native.STM_SGM_FORMS))
         self.form = form
@@ -58,7 +59,8 @@ class Semiglobal:
         # traffic, larger workspace); True: eight separate passes.  Same bits either way.
         self.single_passes = single_passes
         self._workspace = None
-        self._last_tiled = False
+        self._last_tiled = False   # the last call took a tiled form (behind sweeps or walks)
+        self._last_form = _native.STM_SGM_FORM_PAIRED
         # Status word of the last tiled call, on its way to the host (see status()).
         self._status_host = None
         self._status_event = None
@@ -118,7 +120,8 @@ class Semiglobal:
         with torch.cuda.device(device):
             # (form selection and workspace layout depend on the current device's CU count)
             ws_bytes = lib.stm_sgm_workspace_bytes(height, width, max_disparity, batch, flags)
-            self._last_tiled = bool(lib.stm_sgm_uses_tiles(height, width, max_disparity, batch, flags))
+            self._last_form = int(lib.stm_sgm_form(height, width, max_disparity, batch, flags))
+            self._last_tiled = self._last_form != _native.STM_SGM_FORM_PAIRED
             if ws_bytes and (self._workspace is None or self._workspace.device != device
                              or self._workspace.numel() < ws_bytes):
                 self._workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
@@ -147,8 +150,9 @@ class Semiglobal:
     # synchronisation points (Pipeline.status(), distributed.estimate_sharded, bench.py).
     def _post_status(self, device) -> None:
         self._status_event = None
-        if not self._last_tiled or self._workspace is None or self._workspace.numel() < 4:
-            return
+        if (self._last_form != _native.STM_SGM_FORM_SWEEPS or self._workspace is None
+                or self._workspace.numel() < 4):
+            return  # only the row sweeps have waits that can expire
         if torch.cuda.is_current_stream_capturing():
             return  # (a captured call is checked through status(), which reads the device word)
         if self._status_host is None:
@@ -173,8 +177,9 @@ class Semiglobal:
     def status(self) -> int:
         """Status word of the last call (waits for that call): 0 = ok; bit 0 = a bounded wait
         inside the tiled form's row sweeps expired and that call's results are invalid.  The
-        paired form has no waits and always reports 0."""
-        if not self._last_tiled or self._workspace is None or self._workspace.numel() < 4:
+        paired form and the walk-fed tiles have no waits and always report 0."""
+        if (self._last_form != _native.STM_SGM_FORM_SWEEPS or self._workspace is None
+                or self._workspace.numel() < 4):
             return 0
         if self._status_event is not None:
             self._status_event.synchronize()

@@ -213,6 +213,54 @@ static void check_hwalk(const TiledGeom &G, const Ext &E) {
   (void)E;
 }
 
+// Border walks: every path pixel fetch inside the image, every store inside its block, every
+// pixel on exactly one path per direction, and every border line the tiles read is written.
+static void check_bwalk(const TiledGeom &G, const Ext &E) {
+  const int PF = 8, H = G.H, W = G.W;
+  for (int skip = 0; skip < 2; ++skip) {
+    const int n = bwalk_lines(G, skip != 0);
+    std::vector<int> visits((size_t)8 * H * W, 0);
+    for (int l = 0; l < n; ++l) {
+      const WalkLine k = bwalk_line(G, skip != 0, l);
+      CHECK(k.dir >= (skip ? 1 : 0) && k.dir < 8 && k.len >= 1, "line %d: dir %d len %d", l, k.dir, k.len);
+      CHECK(k.index >= 0 && k.index < bwalk_lines_of_dir(G, k.dir), "line index");
+      if (k.dir == 4 || k.dir == 5) CHECK(k.x0 - k.y0 == k.index - (H - 1), "diagonal number = x - y + H - 1");
+      if (k.dir == 6 || k.dir == 7) CHECK(k.x0 + k.y0 == k.index, "anti-diagonal number = x + y");
+      CHECK(bwalk_line_used(G, k.dir, k.index, 1) && (k.dir == 5 || k.dir == 7 || bwalk_line_used(G, k.dir, k.index, 0)),
+            "only inverse diagonals are ever left out");
+      CHECK(k.dx == (k.dir == 0 || k.dir == 4 || k.dir == 7 ? 1 : (k.dir == 2 || k.dir == 3 ? 0 : -1)) &&
+                k.dy == (k.dir < 2 ? 0 : (k.dir == 2 || k.dir == 4 || k.dir == 6 ? 1 : -1)), "step of direction %d", k.dir);
+      const WalkStores st = bwalk_stores(k.dir);
+      int x = k.x0, y = k.y0;
+      for (int i = 0; i < k.len + PF + 64; ++i) in_range(bwalk_pixel(G, k, i), 1, E.pixels, "walk pixel (incl. prefetch)");
+      for (int i = 0; i < k.len; ++i) {
+        CHECK(x >= 0 && x < W && y >= 0 && y < H, "walk position");
+        CHECK(bwalk_pixel(G, k, i) == (unsigned)(y * W + x), "walk pixel index");
+        ++visits[((size_t)k.dir * H + y) * W + x];
+        for (int b = 0; b < G.batch; ++b) {
+          if (st.rk >= 0 && (y & (kT - 1)) == st.rv) check_rowb(G, b, st.rk, y >> 3, x, rowb_off(G, b, st.rk, y >> 3, x), "walk row store");
+          if (st.ck >= 0 && (x & (kT - 1)) == st.cv) check_colb(G, b, st.ck, x >> 3, y, colb_off(G, b, st.ck, x >> 3, y), "walk column store");
+        }
+        // what the tiles read for this direction at this pixel is what the walk stores there
+        bool is_row;
+        const bool on_line = (st.rk >= 0 && (y & 7) == st.rv) || (st.ck >= 0 && (x & 7) == st.cv);
+        if (on_line) {
+          const unsigned off = border_in_image(G, k.dir, x, y, is_row);
+          const long long want = is_row ? (long long)rowb_in_image(G, st.rk, y >> 3, x) : (long long)colb_in_image(G, st.ck, x >> 3, y);
+          CHECK(is_row ? (st.rk >= 0 && (y & 7) == st.rv) : (st.ck >= 0 && (x & 7) == st.cv), "tiles read a line the walk stores");
+          CHECK((long long)off == want, "tiles read where the walk stores (dir %d)", k.dir);
+        }
+        x += k.dx;
+        y += k.dy;
+      }
+      // the step before the first pixel lies outside the image: the path starts at the border
+      CHECK(k.x0 - k.dx < 0 || k.x0 - k.dx >= W || k.y0 - k.dy < 0 || k.y0 - k.dy >= H, "path starts at the image border");
+    }
+    for (int dir = skip ? 1 : 0; dir < 8; ++dir)
+      for (int p = 0; p < H * W; ++p) CHECK(visits[(size_t)dir * H * W + p] == 1, "direction %d visits pixel %d once", dir, p);
+  }
+}
+
 // Which border lines are ever written (by the sweeps, the walks, the D = 128 tile kernel's exits):
 // a tile's entry must point at one of them.
 static bool line_written(int dir, int gx, int gy, bool is_row) {
@@ -256,6 +304,14 @@ static void check_tiles(const TiledGeom &G, const Ext &E) {
                   const int px = inv ? x0 + segs[i].ex + segs[i].n * dx : x0 + segs[i].ex - dx;
                   const int py = inv ? y0 + segs[i].ey + segs[i].n * dy : y0 + segs[i].ey - dy;
                   CHECK(line_written(2 * phase + inv, px, py, e.is_row), "entry of phase %d at (%d, %d) lies on a stored line", phase, px, py);
+                  // an inverse chain that counts (seg_counts) enters from a line the border walks run
+                  if (inv && phase >= 2)
+                    for (int tp = 0; tp < 2; ++tp) {
+                      const Counts c = seg_counts(phase, segs[i], x0, y0, G, tp);
+                      const int line = phase == 2 ? (px - py) + (H - 1) : px + py;
+                      if (c.inv != 0 || c.pre != 0)
+                        CHECK(bwalk_line_used(G, 2 * phase + 1, line, tp), "inverse entry of a counted segment is walked (phase %d, line %d)", phase, line);
+                    }
                 } else {
                   CHECK(e.off == 0 && e.is_row, "dummy entry = first float of the image's row block");
                 }
@@ -316,6 +372,21 @@ static void check_tiles(const TiledGeom &G, const Ext &E) {
     }
     for (int i = 0; i < ntiles; ++i) CHECK(seen[i] == 1, "tile %d visited once (stride %d)", i, stride);
   }
+  for (int by_rows = 0; by_rows < 2; ++by_rows)
+    for (int stride : {1, 5, 512}) {
+      const int nunits = TileUnitWalk::units(G, by_rows != 0);
+      std::vector<int> seen(ntiles, 0);
+      for (int first = 0; first < stride && first < nunits; ++first) {
+        TileUnitWalk t;
+        t.init(first, G, by_rows != 0);
+        while (t.unit < nunits) {
+          CHECK(t.b >= 0 && t.b < G.batch && t.trow >= 0 && t.trow < G.nTR && t.tcol >= 0 && t.tcol < G.nTC, "unit walk position");
+          ++seen[(t.b * G.nTR + t.trow) * G.nTC + t.tcol];
+          t.next(G, stride, by_rows != 0);
+        }
+      }
+      for (int i = 0; i < ntiles; ++i) CHECK(seen[i] == 1, "tile %d visited once by the unit walk (rows %d, stride %d)", i, by_rows, stride);
+    }
   const int nrows = G.batch * G.nTR;
   for (int stride : {1, 2, 7, 512}) {
     std::vector<int> seen(ntiles, 0);
@@ -354,6 +425,7 @@ int main(int argc, char **argv) {
           // the sweeps run when the strips fit the device; the index model does not depend on that
           check_sweeps(G, E);
           check_hwalk(G, E);
+          check_bwalk(G, E);
           check_tiles(G, E);
           ++shapes;
         }

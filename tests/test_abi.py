@@ -18,7 +18,7 @@ def declared_symbols():
 def test_header_declares_the_expected_entry_points():
     assert declared_symbols() == sorted([
         "stm_abi_version", "stm_last_error", "stm_ssd_workspace_bytes", "stm_ssd_f32",
-        "stm_birchfield_f32", "stm_birchfield_ex_f32", "stm_sgm_workspace_bytes", "stm_sgm_uses_tiles",
+        "stm_birchfield_f32", "stm_birchfield_ex_f32", "stm_sgm_workspace_bytes", "stm_sgm_uses_tiles", "stm_sgm_form",
         "stm_sgm_status", "stm_sgm_f32", "stm_sgm_wta_f32", "stm_wta_f32", "stm_dp_f32"])
 
 
@@ -64,4 +64,13 @@ def test_workspace_sizes():
     H, W, D, K = 375, 450, 128, 16
     seg = lambda n: (n + K - 1) // K - 1
     ckpt = H * seg(W) + W * seg(H) + 2 * (W + H - 1) * seg(min(H, W))
-    assert lib.stm_sgm_workspace_bytes(H, W, D, 1, 0) == (H + ckpt) * D * 4
+    paired = 64  # STM_SGM_PAIRED
+    assert lib.stm_sgm_workspace_bytes(H, W, D, 1, paired) == (H + ckpt) * D * 4
+    # A single pair at D = 128 takes the tiles fed by walks (needs no device to decide): header +
+    # mailboxes + 6 / 8 floats of border states per element each for row and column lines.
+    assert lib.stm_sgm_form(H, W, D, 1, 0) == 2 and lib.stm_sgm_form(H, W, 64, 1, 0) == 0
+    assert lib.stm_sgm_form(H, W, D, 1, paired) == 0 and lib.stm_sgm_form(H, W, D, 1, 512) == 2
+    nTR, nTC, strips = (H + 7) // 8, (W + 7) // 8, (W + 63) // 64
+    tiled = (64 + 2 * strips * 2 * 4 * D * 2 + 6 * nTR * W * D + 6 * nTC * H * D) * 4
+    assert lib.stm_sgm_workspace_bytes(H, W, D, 1, 512) == tiled
+    assert lib.stm_sgm_workspace_bytes(H, W, D, 1, 0) == max(tiled, 256 + (H + ckpt) * D * 4)

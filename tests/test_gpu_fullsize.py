@@ -203,8 +203,7 @@ def test_teddy_large_batch_takes_the_tiled_form_and_matches_single_pairs(device,
     from stereomatch import _native
     g = GOLDEN["teddy 375x450x128"]
     H, W, D, B = g["H"], g["W"], g["D"], 48
-    assert _native.lib().stm_sgm_uses_tiles(H, W, D, B, 0) == 1, "the batch should take the tiled form"
-    assert _native.lib().stm_sgm_uses_tiles(H, W, D, 1, 0) == 0
+    assert _native.lib().stm_sgm_form(H, W, D, B, 0) == _native.STM_SGM_FORM_SWEEPS, "the batch should take the sweep-fed tiled form"
     pairs = [oracle.synthetic_pair(H, W, seed=s) for s in range(B)]
     Lb = torch.from_numpy(np.stack([p[0] for p in pairs])).to(device)
     Rb = torch.from_numpy(np.stack([p[1] for p in pairs])).to(device)
@@ -218,7 +217,7 @@ def test_teddy_large_batch_takes_the_tiled_form_and_matches_single_pairs(device,
     assert sgm.status() == 0
     assert digest16(Cb[0]) == g["ssd"] and digest16(Sb[0]) == g["sgm"]
     assert digest16(fused_b[0]) == g["ssd_sgm_wta"]
-    sgm1 = stereomatch.aggregation.Semiglobal()
+    sgm1 = stereomatch.aggregation.Semiglobal(form="paired")
     S1 = None
     for b in range(B):
         S1 = sgm1(Cb[b], Lb[b], S1)

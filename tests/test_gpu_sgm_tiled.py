@@ -25,19 +25,21 @@ TILED_CASES = [
 ]
 
 
-def _tiled(**kw):
+def _tiled(form="tiled", **kw):
     import stereomatch
-    return stereomatch.aggregation.Semiglobal(form="tiled", **kw)
+    return stereomatch.aggregation.Semiglobal(form=form, **kw)
 
 
+# form "tiled": border states from row sweeps; "walks": from per-path walks (stm_sgm_bwalk.hip)
 @pytest.mark.parametrize("H,W,D", TILED_CASES)
 @pytest.mark.parametrize("kind", ["float", "last"])
-def test_tiled_sgm_matches_oracle(device, oracle, H, W, D, kind):
+@pytest.mark.parametrize("form", ["tiled", "walks"])
+def test_tiled_sgm_matches_oracle(device, oracle, H, W, D, kind, form):
     rng = np.random.default_rng(13 * H + 7 * W + D)
     C = _random_volume(rng, H, W, D, kind)
     image = rng.integers(0, 5, size=(H, W)).astype(np.float32)
     want = oracle.sgm(C, image, 0.5, 3.0)
-    sgm = _tiled(penalty1=0.5, penalty2=3.0)
+    sgm = _tiled(form, penalty1=0.5, penalty2=3.0)
     got = sgm(_gpu(C, device), _gpu(image, device))
     assert sgm.status() == 0
     assert_same_bits(got.cpu().numpy(), want, "tiled sgm " + kind)
@@ -52,12 +54,13 @@ def test_tiled_sgm_matches_oracle(device, oracle, H, W, D, kind):
 @pytest.mark.parametrize("H,W,D", [(24, 40, 64), (40, 24, 64), (33, 70, 128), (70, 33, 256)])
 @pytest.mark.parametrize("paths", ["reference", "hirschmuller"])
 @pytest.mark.parametrize("full_min", [False, True])
-def test_tiled_sgm_corrected_modes(device, oracle, H, W, D, paths, full_min):
+@pytest.mark.parametrize("form", ["tiled", "walks"])
+def test_tiled_sgm_corrected_modes(device, oracle, H, W, D, paths, full_min, form):
     rng = np.random.default_rng(H + W + D)
     C = _random_volume(rng, H, W, D, "ties")
     image = rng.integers(0, 4, size=(H, W)).astype(np.float32)
     want = oracle.sgm(C, image, 0.1, 0.2, full_min=full_min, true_paths=(paths == "hirschmuller"))
-    sgm = _tiled(paths=paths, full_min=full_min)
+    sgm = _tiled(form, paths=paths, full_min=full_min)
     got = sgm(_gpu(C, device), _gpu(image, device))
     assert sgm.status() == 0
     assert_same_bits(got.cpu().numpy(), want, "tiled sgm %s full_min=%s" % (paths, full_min))
@@ -65,7 +68,8 @@ def test_tiled_sgm_corrected_modes(device, oracle, H, W, D, paths, full_min):
 
 @pytest.mark.parametrize("H,W,D,B", [(14, 31, 64, 3), (31, 14, 64, 3), (40, 300, 64, 70), (20, 500, 256, 20),
                                      (40, 90, 128, 5), (100, 60, 128, 50), (60, 100, 128, 9)])
-def test_tiled_sgm_batches(device, oracle, H, W, D, B):
+@pytest.mark.parametrize("form", ["tiled", "walks"])
+def test_tiled_sgm_batches(device, oracle, H, W, D, B, form):
     """Batches: per-image mailboxes and border states; (40, 300) and (20, 500) need several sweep
     launches (more column strips than the chip has CUs); the D = 128 cases run the tile kernel
     whose workgroups own whole tile rows (more rows than workgroups in (100, 60, 128, 50))."""
@@ -74,7 +78,7 @@ def test_tiled_sgm_batches(device, oracle, H, W, D, B):
     C = np.stack([_random_volume(rng, H, W, D, "float") for _ in range(B)])
     image = rng.integers(0, 5, size=(B, H, W)).astype(np.float32)
     Cg, Ig = _gpu(C, device), _gpu(image, device)
-    sgm = _tiled()
+    sgm = _tiled(form)
     S = sgm(Cg, Ig)
     assert sgm.status() == 0
     ref = stereomatch.aggregation.Semiglobal(form="paired")(Cg, Ig)
@@ -122,8 +126,8 @@ def _fuzz_cases(n, seed):
     return cases
 
 
-@pytest.mark.parametrize("seed", [11, 12, 13])
-def test_tiled_fuzz_against_paired(device, seed):
+@pytest.mark.parametrize("seed,form", [(11, "tiled"), (12, "tiled"), (13, "tiled"), (14, "walks"), (15, "walks")])
+def test_tiled_fuzz_against_paired(device, seed, form):
     """Random shapes, batches and options: the tiled form against the paired form (which the
     other tests hold against the oracle), sum volume and fused disparities, bit for bit."""
     import stereomatch
@@ -133,7 +137,7 @@ def test_tiled_fuzz_against_paired(device, seed):
         image = rng.integers(0, 6, size=(B, H, W)).astype(np.float32)
         Cg, Ig = _gpu(C, device), _gpu(image, device)
         kw = dict(penalty1=0.25, penalty2=2.0, paths=paths, full_min=full_min)
-        t = stereomatch.aggregation.Semiglobal(form="tiled", **kw)
+        t = stereomatch.aggregation.Semiglobal(form=form, **kw)
         p = stereomatch.aggregation.Semiglobal(form="paired", **kw)
         what = "H=%d W=%d D=%d B=%d %s %s full_min=%s" % (H, W, D, B, kind, paths, full_min)
         if os.environ.get("STM_FUZZ_VERBOSE"):
@@ -151,3 +155,31 @@ def test_tiled_fuzz_against_paired(device, seed):
         _, dt = t.aggregate_and_reduce(Cg, Ig)
         _, dp_ = p.aggregate_and_reduce(Cg, Ig)
         assert torch.equal(dt, dp_), "fused disparities: " + what
+
+
+def test_auto_form_picks_walks_for_single_pairs_and_sweeps_for_batches(device):
+    """What `auto` selects (stm_sgm_uses_tiles + the flags): a single Teddy- or 1080p-sized pair
+    takes the tiled form (fed by walks: its status word exists and stays 0), D = 64 the paired
+    form; forcing a form through the flags is honoured."""
+    from stereomatch import _native
+    lib = _native.lib()
+    assert lib.stm_sgm_uses_tiles(375, 450, 128, 1, 0) == 1
+    assert lib.stm_sgm_uses_tiles(1080, 1920, 256, 1, 0) == 1
+    assert lib.stm_sgm_uses_tiles(375, 450, 128, 256, 0) == 1
+    assert lib.stm_sgm_uses_tiles(375, 450, 64, 1, 0) == 0
+    assert lib.stm_sgm_uses_tiles(375, 450, 128, 1, _native.STM_SGM_FORMS["paired"]) == 0
+    assert lib.stm_sgm_uses_tiles(20, 22, 64, 1, _native.STM_SGM_FORMS["walks"]) == 1
+    assert lib.stm_sgm_uses_tiles(12, 20, 48, 1, _native.STM_SGM_FORMS["walks"]) == 0
+
+
+def test_single_pair_default_path_matches_oracle(device, oracle):
+    """The reference's call shape -- one pair, defaults -- through Pipeline (auto form: tiles fed
+    by walks at D = 128), against the oracle."""
+    import stereomatch
+    H, W, D = 96, 130, 128
+    L, R = oracle.synthetic_pair(H, W, seed=5)
+    pipe = stereomatch.Pipeline(stereomatch.cost.SSD(D), stereomatch.disparity_reduce.WinnerTakesAll(),
+                                stereomatch.aggregation.Semiglobal())
+    got = pipe.estimate(_gpu(L, device), _gpu(R, device))
+    assert pipe.status() == 0 and pipe.aggregation._last_tiled
+    assert_same_bits(got.cpu().numpy(), oracle.wta(oracle.sgm(oracle.ssd(L, R, D), L)), "single pair, auto form")

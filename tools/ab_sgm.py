@@ -19,6 +19,8 @@ from stereomatch import _native
 def load(path):
     h = ctypes.CDLL(os.path.abspath(path))
     for name, (restype, argtypes) in _native.PROTOTYPES.items():
+        if not hasattr(h, name):  # an older build of the library
+            continue
         fn = getattr(h, name)
         fn.restype = restype
         fn.argtypes = argtypes
@@ -67,6 +69,11 @@ def main():
                 return
             if op == "bt":
                 rc = libs[i].stm_birchfield_f32(left.data_ptr(), right.data_ptr(), scratch.data_ptr(), H, W, D, B, s)
+                assert rc == 0, libs[i].stm_last_error()
+                return
+            if op == "sgm":  # unfused: the aggregated volume is written
+                rc = libs[i].stm_sgm_f32(cost.data_ptr(), image.data_ptr(), scratch.data_ptr(), H, W, D, 0.1, 0.2,
+                                         0, ws.data_ptr(), ws.numel(), B, s)
                 assert rc == 0, libs[i].stm_last_error()
                 return
             if op == "wta":

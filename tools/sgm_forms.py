@@ -26,7 +26,7 @@ def main():
     R = torch.from_numpy(np.ascontiguousarray(base[:, :, 39:39 + W])).to(dev)
     C = stereomatch.cost.SSD(D)(L, R)
     res = {}
-    for form in ("paired", "tiled"):
+    for form in ("paired", "tiled", "walks"):
         sgm = stereomatch.aggregation.Semiglobal(form=form)
         for fused in (True, False):
             vol = disp = None
@@ -49,9 +49,10 @@ def main():
                      8.0 * n / t / 1e6 / 8000.0, sgm.status()), flush=True)
         del sgm
         torch.cuda.empty_cache()
-    print("fused disparities equal:", bool(torch.equal(res[("paired", True)], res[("tiled", True)])))
-    print("unfused volumes equal:  ", bool(torch.equal(res[("paired", False)].view(torch.int32),
-                                                        res[("tiled", False)].view(torch.int32))))
+    for form in ("tiled", "walks"):
+        print(form, "fused disparities equal:", bool(torch.equal(res[("paired", True)], res[(form, True)])),
+              " unfused volumes equal:", bool(torch.equal(res[("paired", False)].view(torch.int32),
+                                                          res[(form, False)].view(torch.int32))))
 
 
 if __name__ == "__main__":
