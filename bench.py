@@ -383,6 +383,12 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
+    # Exactly ONE line on stdout: everything libraries print there while the job runs (RCCL's
+    # version banner, gloo's connection notes) goes to stderr instead; the JSON line is written to
+    # the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     form = args.form or ("paired" if args.shared_device else "auto")
 
     global GATHER_MODE
@@ -525,8 +531,9 @@ def main():
         dist.barrier()
     if dist.is_available() and dist.is_initialized():  # also the 1-rank RCCL rehearsal group
         dist.destroy_process_group()
+    sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -89,9 +89,10 @@ def main():
             groups, cur = [], None
             for r in rows:
                 k = short(r["Kernel_Name"])
-                if k.startswith("sgm_ckpt_kernel") or k.startswith("sgm_hwalk_kernel"):
+                if k.startswith(("sgm_ckpt_kernel", "sgm_hwalk_kernel", "sgm_bwalk_kernel")):
                     cur = {"vpl": k, "bytes": 0.0, "fused": False,
-                           "form": "tiled" if k.startswith("sgm_hwalk") else "paired"}
+                           "form": "tiled (sweeps)" if k.startswith("sgm_hwalk") else
+                                   ("tiled (walks)" if k.startswith("sgm_bwalk") else "paired")}
                     groups.append(cur)
                 if cur is None:
                     continue

@@ -688,3 +688,31 @@ def test_float64_is_declined_with_the_reference_dispatch_named(device):
     # Birchfield casts its images like the reference wrapper (cost.py:98-99): float64 in, float32 out.
     out = stereomatch.cost.Birchfield(16)(img.double(), img.double())
     assert out.dtype == torch.float32
+
+
+@pytest.mark.parametrize("H,W,D,mode", [(40, 48, 32, "reference"), (40, 70, 128, "corrected"), (300, 320, 256, "reference")])
+def test_dp_nan_contract(device, oracle, H, W, D, mode):
+    """Non-finite inputs of the dynamic programming, as DESIGN.md section 2 documents them: +inf
+    costs are the reference's bit for bit (tested above); a NaN is an operand the kernel's
+    three-way minimum IGNORES (v_min_f32) where the reference's strict-'<' chain
+    (src/dynamic_programming.cu:50-59) lets it decide -- so a row that holds a NaN may differ
+    from the reference, and only such a row: rows are independent, every other row of the volume
+    is the reference's in disparity, path record and final costs, and the affected rows still
+    produce valid records (directions in {-1, 0, 1}, disparities in [0, D))."""
+    import stereomatch
+    rng = np.random.default_rng(H + W + D)
+    C = (rng.random((H, W, D)) * 30).astype(np.float32)
+    clean = C.copy()
+    bad_rows = sorted(rng.choice(np.arange(D if mode == "reference" else 0, H), size=3, replace=False).tolist())
+    for r in bad_rows:  # (reference mode reads cost[d][row][0] of rows < D for every row: keep those clean)
+        C[r, rng.integers(1, W, size=5), rng.integers(0, D, size=5)] = np.nan
+    dp = stereomatch.disparity_reduce.DynamicProgramming(mode=mode)
+    got = dp(_gpu(C, device)).cpu().numpy()
+    path = dp.path_volume.cpu().numpy()
+    want, wpath, wfin = oracle.dp(clean, mode={"reference": 0, "corrected": 1}[mode], return_aux=True)
+    good = np.array([r not in bad_rows for r in range(H)])
+    assert np.array_equal(got[good], want[good]), "rows without a NaN equal the reference"
+    assert got.min() >= 0 and got.max() < D
+    assert np.array_equal(path[good], wpath[good])
+    assert set(np.unique(path[~good]).tolist()) <= {-1, 0, 1}
+    assert_same_bits(dp.row_final_costs.cpu().numpy()[good], wfin[good], "final costs of the rows without a NaN")

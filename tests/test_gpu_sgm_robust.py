@@ -236,3 +236,29 @@ def test_failed_call_is_reported_by_the_next_call(device):
         sgm(C, I)
     sgm(C, I)  # the report is delivered once
     assert sgm.status() == 0
+
+
+def test_tiled_forms_fall_back_where_they_do_not_apply(device, oracle):
+    """Where the tiled forms stop (include/stereomatch_hip.h): D other than 64 / 128 / 256 (e.g.
+    the reference limit's D = 512, src/semiglobal_gpu.cu:109-120), SINGLE_PASSES and
+    EXACT_NONFINITE.  form="tiled" / "walks" then silently take the paired form -- same results,
+    the flag only ever changes speed -- and stm_sgm_form says so."""
+    import stereomatch
+    from stereomatch import _native
+    lib = _native.lib()
+    for D in (192, 512, 1024):
+        for form in ("tiled", "walks"):
+            assert lib.stm_sgm_form(64, 96, D, 4, _native.STM_SGM_FORMS[form]) == _native.STM_SGM_FORM_PAIRED
+    for extra in (_native.STM_SGM_SINGLE_PASSES, _native.STM_SGM_EXACT_NONFINITE):
+        assert lib.stm_sgm_form(64, 96, 128, 4, _native.STM_SGM_FORMS["tiled"] | extra) == _native.STM_SGM_FORM_PAIRED
+    assert lib.stm_sgm_form(64, 96, 128, 4, _native.STM_SGM_FORMS["tiled"] | _native.STM_SGM_ACCUMULATE) == _native.STM_SGM_FORM_SWEEPS
+    rng = np.random.default_rng(9)
+    H, W, D = 20, 36, 512
+    C = _random_volume(rng, H, W, D, "float")
+    image = rng.integers(0, 5, size=(H, W)).astype(np.float32)
+    want = oracle.sgm(C, image, 0.5, 3.0)
+    for form in ("tiled", "walks", "auto"):
+        sgm = stereomatch.aggregation.Semiglobal(0.5, 3.0, form=form)
+        got = sgm(_gpu(C, device), _gpu(image, device))
+        assert sgm.status() == 0 and not sgm._last_tiled
+        assert_same_bits(got.cpu().numpy(), want, "D = 512, form=" + form)
