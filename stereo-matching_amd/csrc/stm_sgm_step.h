@@ -482,81 +482,6 @@ __device__ __forceinline__ void sgm_step_h2x3(Row<4> (&p)[3], const Row<4> (&c)[
 }
 
 // ---------------------------------------------------------------------------------
-// Four pixels per wave (D = 128): every 16-lane DPP row holds one pixel's disparities, eight per
-// lane, and one instruction sequence steps four paths.
-//
-// Against the two-pixel form above the cross-lane part shrinks from twelve instructions per two
-// pixels to seven per four: the minimum over a pixel's sixteen lanes is four in-row DPP stages that
-// leave the result in every lane (no v_permlane16_swap, no copy), the neighbour values L(d -+ 1)
-// are one row shift each (lanes 0 / 15 of a row have no source and keep their +inf), the penalty
-// arrives by row_newbcast.  ~35 instead of ~52 SIMD cycles per pixel-step; the tile kernel that
-// uses it is bound by vector instructions issued (rocprof: 72 % VALU-active at two waves per SIMD,
-// 2,700 instructions per tile and wave, 69 % of them chain steps).  Same operations on the same
-// operands per pixel -> same bits.
-// ---------------------------------------------------------------------------------
-struct StepCtxH4 {
-  float p1;            // P1 (scalar operand of the adds)
-  float p1v;           // ... and in a VGPR (DPP operands must be)
-  float below, above;  // lane 0 of every row of `below` and lane 15 of `above` stay +inf
-  bool drop_tail;      // this lane's last element is d = D-1 and the reference minimum leaves it out (Q5)
-  __device__ __forceinline__ void init(float p1_, int l16, int dlim) {
-    p1 = p1_;
-    p1v = in_vgpr(p1_);
-    below = above = in_vgpr(__builtin_inff());
-    drop_tail = l16 == 15 && dlim < 128;
-  }
-};
-
-// One step for the four rows (semiglobal.cpp:129-157).  `pen` holds the penalties P2' of the
-// lane's row, one per lane; PEN_LANE selects this step's.  The DPP stages of the minimum are
-// dependent (two wait states each): the step's own independent adds fill them.
-template <int PEN_LANE>
-__device__ __forceinline__ void sgm_step_h4(Row<8> &p, const Row<8> &c, float pen, StepCtxH4 &X) {
-  static_assert(!kExactNonFinite, "the exact non-finite variant uses sgm_step");
-  const float inf = __builtin_inff();
-  float m = X.drop_tail ? inf : p.v[7];
-  m = vmin3_f32(m, p.v[0], p.v[1]);
-  m = vmin3_f32(m, p.v[2], p.v[3]);
-  m = vmin3_f32(m, p.v[4], p.v[5]);
-  m = vmin_f32(m, p.v[6]);
-  float w[8], far;
-  // %0 m; %1-%8 w; %9 below; %10 above; %11 far; %12-%19 p; %20 pen; %21 p1v; %22 p1; %23 PEN_LANE
-  asm("v_add_f32 %1, %22, %12\n\t"
-      "v_add_f32 %2, %22, %13\n\t"
-      "v_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32 %3, %22, %14\n\t"
-      "v_add_f32 %4, %22, %15\n\t"
-      "v_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32 %5, %22, %16\n\t"
-      "v_add_f32 %6, %22, %17\n\t"
-      "v_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32 %7, %22, %18\n\t"
-      "v_add_f32 %8, %22, %19\n\t"
-      "v_min_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %9, %19, %21 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %10, %12, %21 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %11, %20, %0 row_newbcast:%23 row_mask:0xf bank_mask:0xf"
-      : "+v"(m), "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]),
-        "=&v"(w[7]), "+v"(X.below), "+v"(X.above), "=&v"(far)
-      : "v"(p.v[0]), "v"(p.v[1]), "v"(p.v[2]), "v"(p.v[3]), "v"(p.v[4]), "v"(p.v[5]), "v"(p.v[6]), "v"(p.v[7]),
-        "v"(pen), "v"(X.p1v), "s"(X.p1), "n"(PEN_LANE));
-  float t[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float lo = j == 0 ? X.below : w[j - 1];
-    const float hi = j == 7 ? X.above : w[j + 1];
-    t[j] = vmin_f32(vmin3_f32(p.v[j], lo, hi), far);
-  }
-#pragma unroll
-  for (int j = 0; j < 8; j += 2) {
-    const f32x2 m2 = {m, m};
-    const f32x2 r = (f32x2{c.v[j], c.v[j + 1]} + f32x2{t[j], t[j + 1]}) - m2;
-    p.v[j] = r.x;
-    p.v[j + 1] = r.y;
-  }
-}
-
-// ---------------------------------------------------------------------------------
 // One step with its front half scheduled by hand (whole lanes only; VPL = 2 or 4).
 //
 // In sgm_step every DPP instruction of the six-stage wave minimum sits behind an s_nop 1 (two

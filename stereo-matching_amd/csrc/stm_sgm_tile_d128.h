@@ -1,7 +1,8 @@
-// Pieces shared by the two D = 128 tile kernels (stm_sgm_tile_h2.hip: two lines of a pair per
-// wave; stm_sgm_tile_h4.hip: two lines with their forward and inverse chains side by side): the
-// lines a wave owns, a tile's terms of the entry addresses, and the one-line-per-wave forms that
-// the tiles on the image border and on the reference's re-walked diagonals take.
+// Pieces of the D = 128 tile kernel (stm_sgm_tile_h2.hip) that do not depend on how a wave steps
+// its lines: the lines a wave owns, a tile's terms of the entry addresses, and the
+// one-line-per-wave forms that the tiles on the image border take.  (A second kernel on top of
+// them -- four pixels per wave, forward | inverse chains in the two wave halves -- was measured
+// and is in the history only: DESIGN.md section 9.)
 #pragma once
 
 #include "stm_sgm_tile_common.h"

@@ -209,12 +209,8 @@ int sgm_run_tiled(const float *cost, const float *left, float *out, int32_t *dis
       rc = tiled_launch_sweep(cost, left, ws, c, up != 0, stream);
   }
   if (rc != STM_OK || (skip & 4)) return rc;
-  if (D == 128) {
-    static const bool h2 = getenv("STM_TILE_H2") != nullptr;  // development: the two-pixels-per-wave kernel, for A/B
-    return h2 ? tiled_launch_tiles_h2(cost, left, out, disp, ws, c, final_mode, stream)
-              : tiled_launch_tiles_h4(cost, left, out, disp, ws, c, final_mode, stream);
-  }
-  return tiled_launch_tiles(cost, left, out, disp, ws, c, final_mode, stream);
+  return D == 128 ? tiled_launch_tiles_h2(cost, left, out, disp, ws, c, final_mode, stream)
+                  : tiled_launch_tiles(cost, left, out, disp, ws, c, final_mode, stream);
 }
 
 }  // namespace stm

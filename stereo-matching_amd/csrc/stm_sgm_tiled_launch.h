@@ -38,8 +38,5 @@ int tiled_launch_tiles(const float *cost, const float *left, float *out, int32_t
                        const TiledCall &c, int final_mode, hipStream_t s);
 int tiled_launch_tiles_h2(const float *cost, const float *left, float *out, int32_t *disp, float *ws,
                           const TiledCall &c, int final_mode, hipStream_t s);
-// stm_sgm_tile_h4.hip (D = 128, four pixels per wave).
-int tiled_launch_tiles_h4(const float *cost, const float *left, float *out, int32_t *disp, float *ws,
-                          const TiledCall &c, int final_mode, hipStream_t s);
 
 }  // namespace stm
