@@ -296,6 +296,25 @@ __device__ __forceinline__ void buf_store_row(BufRsrc r, int voff, int soff, con
   }
 }
 
+// Loads / stores of data that another workgroup of the SAME launch has written / will read:
+// relaxed atomics at agent scope, dword by dword (sc1 accesses: served by / written through to
+// the memory side.  MI355X guide, Guideline 16: the per-XCD L2s are not coherent with each
+// other).  For hand-overs that happen once per thousands of pixels; ordering against the flag
+// that announces them is the caller's (s_waitcnt + release on one side, acquire on the other).
+template <int VPL>
+__device__ __forceinline__ Row<VPL> load_row_agent(const float *p) {
+  Row<VPL> o;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j)
+    o.v[j] = __hip_atomic_load(const_cast<float *>(p) + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return o;
+}
+template <int VPL>
+__device__ __forceinline__ void store_row_agent(float *p, const Row<VPL> &x) {
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) __hip_atomic_store(p + j, x.v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 #endif  // __HIPCC__
 
 }  // namespace stm

@@ -32,7 +32,10 @@ struct TileArgs {
   int dlim;
   int true_paths;
   int accumulate;  // STM_SGM_ACCUMULATE: the sum starts from the caller's contents of `out`, not from 0
-  int by_rows;     // D = 128 kernel: workgroups own whole tile rows and carry the rightward state along them
+  int by_rows;     // workgroups own tile rows (D = 128) / row segments (D = 64, 256) and carry the rightward
+                   // state along them; no walk of that direction has run
+  int segs;        // D = 64, 256: segments per tile row (row_segs)
+  long long status_off;  // the workspace header (status word, ticket counter)
   unsigned long long *stamps;  // diagnostic builds only (stm_sgm_tiled_diag.h), else null
 };
 
@@ -401,7 +404,7 @@ __device__ __forceinline__ void tile_pair(const PhaseGeom &g, const Entries<VPL,
                                           const float *Ct, float *St, const float *Ip, const TileArgs &P,
                                           int x0, int y0, float *__restrict__ out,
                                           int32_t *__restrict__ disp, StepCtx &X, int lane,
-                                          Between between) {
+                                          Between between, Row<VPL> *exit_f = nullptr) {
   Row<VPL> LF[kT], LI[kT];
   Slots<PHASE> sl;
   sl.init(g);
@@ -420,10 +423,12 @@ __device__ __forceinline__ void tile_pair(const PhaseGeom &g, const Entries<VPL,
   }
   if (fast) {
     tile_chains_fast<VPL, PHASE>(sl, E, inv_a, inv_b, Ct, Ip, P.p1, P.p2, X, lane, LF, LI);
+    if (PHASE == 0 && exit_f) *exit_f = LF[kT - 1];
     between();
     tile_add_fast<VPL, PHASE, FINAL>(sl, LF, LI, inv_a, inv_b, St, P.G, P.accumulate != 0, x0, y0, out, disp, lane);
   } else {
     tile_chains<VPL, PHASE>(sl, E, Ct, Ip, P.p1, P.p2, X, lane, LF, LI);
+    if (PHASE == 0 && exit_f) *exit_f = LF[kT - 1];  // (the row's rightward exit where it spans the tile: nT == 8)
     between();
     tile_add<VPL, PHASE, FINAL>(g, sl, LF, LI, St, P, x0, y0, out, disp, lane);
   }

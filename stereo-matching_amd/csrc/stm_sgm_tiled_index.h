@@ -26,7 +26,9 @@ namespace tiled {
 constexpr int kT = 8;            // tile side = spacing of the stored border lines
 constexpr int kSweepWaves = 16;  // waves per sweep workgroup (one workgroup per CU)
 constexpr int kMboxSlots = 4;    // rows of history per mailbox
-constexpr int kHeaderFloats = 64;  // 256 bytes: status word + padding (16-byte alignment of what follows)
+constexpr int kHeaderFloats = 64;  // 256 bytes: status word, ticket counter, padding (16-byte alignment of what follows)
+constexpr int kTicketWord = 1;     // 32-bit word of the header: the tile kernel's unit counter (row segments)
+constexpr int kMaxSegs = 4;        // segments a tile row may be cut into (row_segs)
 
 STM_HD int imin_(int a, int b) { return a < b ? a : b; }
 STM_HD int imax_(int a, int b) { return a > b ? a : b; }
@@ -39,6 +41,7 @@ struct TiledGeom {
   long long colb_off;    // [batch][6][nTC][H][D]: ->, dr, ur (columns x%8==7), <-, dl, ul (x%8==0)
   long long rowb_img, colb_img;
   long long mbox_off;    // [2 sweeps][batch][strips][2 sides][kMboxSlots][D] granules (8 bytes each)
+  long long flag_off;    // [batch][nTR][kMaxSegs] 32-bit flags: segment of a tile row finished (row_segs)
   int strips;            // column strips per image in the sweeps
   int batch;
 };
@@ -61,6 +64,8 @@ STM_HD bool make_geom(int H, int W, int D, int batch, TiledGeom &G, long long &t
   long long off = kHeaderFloats;
   G.mbox_off = off;
   off += 2ll * batch * G.strips * 2 * kMboxSlots * D * 2;  // granules are two floats wide
+  G.flag_off = off;
+  off += ((long long)batch * G.nTR * kMaxSegs + 3) / 4 * 4;  // (keeps what follows 16-byte aligned)
   zero_floats = off;
   G.rowb_off = off;
   G.rowb_img = 6ll * G.nTR * W * D;
@@ -421,6 +426,45 @@ struct TileUnitWalk {
     }
   }
 };
+// Tile rows cut into segments (the D = 64 / 256 tile kernel behind row sweeps): a workgroup takes
+// a segment, walks its tiles left to right and carries the left-to-right state in registers,
+// so that direction needs no walk of its own -- one read of the cost volume fewer.  A whole row
+// per workgroup would leave 1,080 rows of eight 1080p pairs to 256 workgroups (five rounds for
+// 4.2 rounds of work); segments are units of a finer grain, handed out by an atomic ticket in
+// the order "all first segments, all second segments, ...".  A segment that is not the first of
+// its row starts from the state its left neighbour left in the column border states and waits
+// for that neighbour's flag; the neighbour's ticket is lower, so it is held by a workgroup that
+// is running or done, and first segments wait for nobody: no residency requirement, no deadlock.
+struct RowSegs {
+  int len, nseg;  // tiles per segment, segments per row (the last one may be shorter)
+};
+STM_HD RowSegs row_segs(const TiledGeom &G, int segs) {
+  RowSegs r;
+  const int want = imax_(1, imin_(segs, kMaxSegs));
+  r.len = (G.nTC + want - 1) / want;
+  r.nseg = (G.nTC + r.len - 1) / r.len;
+  return r;
+}
+struct SegUnit {
+  int b, trow, seg, tbeg, tend;  // image, tile row, segment and its tile columns [tbeg, tend)
+};
+STM_HD int seg_units(const TiledGeom &G, const RowSegs &r) { return r.nseg * G.batch * G.nTR; }
+STM_HD SegUnit seg_unit(const TiledGeom &G, const RowSegs &r, int unit) {
+  const int nrows = G.batch * G.nTR;
+  SegUnit u;
+  u.seg = unit / nrows;
+  const int row = unit - u.seg * nrows;
+  u.b = row / G.nTR;
+  u.trow = row - u.b * G.nTR;
+  u.tbeg = u.seg * r.len;
+  u.tend = imin_(G.nTC, u.tbeg + r.len);
+  return u;
+}
+// Index of a segment's flag (32-bit words from G.flag_off).
+STM_HD long long seg_flag_index(const TiledGeom &G, int b, int trow, int seg) {
+  return ((long long)b * G.nTR + trow) * kMaxSegs + seg;
+}
+
 // A tile all of whose neighbours exist (every line enters from a border state).
 STM_HD bool tile_interior(const TiledGeom &G, int trow, int tcol) {
   return trow >= 1 && trow <= G.nTR - 2 && tcol >= 1 && tcol <= G.nTC - 2 && (trow + 1) * kT <= G.H &&

@@ -15,8 +15,9 @@ struct TiledCall {
   int true_paths;     // STM_SGM_TRUE_PATHS
   int accumulate;     // STM_SGM_ACCUMULATE
   bool cooperative;   // STM_SGM_COOPERATIVE
-  bool by_rows;       // D = 128 behind sweeps: the tile kernel owns tile rows and carries the
-                      // left-to-right state itself (no walk of that direction)
+  bool by_rows;       // behind sweeps: the tile kernel owns tile rows (D = 128) / row segments and carries
+                      // the left-to-right state itself (no walk of that direction)
+  int segs;           // D = 64, 256: segments per tile row
   long long status_off;
   int group;          // images per sweep launch
   int cus;

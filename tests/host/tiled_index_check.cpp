@@ -44,7 +44,10 @@ struct Ext {
 
 static void check_layout(const TiledGeom &G, long long total, long long zero) {
   CHECK(G.mbox_off == kHeaderFloats, "mailboxes start behind the header");
-  CHECK(G.mbox_off + 2 * mbox_granules(G) == zero, "zeroed head = header + mailboxes");
+  CHECK(G.flag_off == G.mbox_off + 2 * mbox_granules(G), "flags behind the mailboxes");
+  CHECK(zero >= G.flag_off + (long long)G.batch * G.nTR * kMaxSegs && zero - G.flag_off - (long long)G.batch * G.nTR * kMaxSegs < 4,
+        "zeroed head = header + mailboxes + flags");
+  CHECK(kTicketWord < kHeaderFloats, "ticket word inside the header");
   CHECK(G.rowb_off == zero && G.colb_off == G.rowb_off + G.rowb_img * G.batch, "regions in order");
   CHECK(G.colb_off + G.colb_img * G.batch == total, "workspace size");
   CHECK(G.mbox_off % 4 == 0 && G.rowb_off % 4 == 0 && G.colb_off % 4 == 0 && G.rowb_img % 4 == 0 && G.colb_img % 4 == 0,
@@ -387,6 +390,25 @@ static void check_tiles(const TiledGeom &G, const Ext &E) {
       }
       for (int i = 0; i < ntiles; ++i) CHECK(seen[i] == 1, "tile %d visited once by the unit walk (rows %d, stride %d)", i, by_rows, stride);
     }
+  // row segments: every tile in exactly one unit, units in the order "first segments first",
+  // flags inside their region, a segment's left neighbour has a lower unit number
+  for (int segs = 1; segs <= kMaxSegs + 1; ++segs) {
+    const RowSegs rs = row_segs(G, segs);
+    CHECK(rs.nseg >= 1 && rs.nseg <= kMaxSegs && rs.len >= 1, "segments per row");
+    std::vector<int> seen(ntiles, 0);
+    const int nu = seg_units(G, rs);
+    for (int u = 0; u < nu; ++u) {
+      const SegUnit q = seg_unit(G, rs, u);
+      CHECK(q.b >= 0 && q.b < G.batch && q.trow >= 0 && q.trow < G.nTR && q.seg >= 0 && q.seg < rs.nseg, "unit %d", u);
+      CHECK(q.tbeg < q.tend && q.tend <= G.nTC, "unit %d is not empty: [%d, %d)", u, q.tbeg, q.tend);
+      CHECK(seg_flag_index(G, q.b, q.trow, q.seg) < (long long)G.batch * G.nTR * kMaxSegs, "flag index");
+      if (q.seg > 0) CHECK(u - G.batch * G.nTR >= 0 && seg_unit(G, rs, u - G.batch * G.nTR).tend == q.tbeg, "left neighbour = unit - rows");
+      for (int t = q.tbeg; t < q.tend; ++t) ++seen[(q.b * G.nTR + q.trow) * G.nTC + t];
+      // where a segment that is not the last of its row leaves its states: column tcol = tend - 1, full width
+      if (q.tend < G.nTC) CHECK(q.tend * kT <= G.W, "a segment ends at a full tile");
+    }
+    for (int i = 0; i < ntiles; ++i) CHECK(seen[i] == 1, "tile %d in one segment (segs %d)", i, segs);
+  }
   const int nrows = G.batch * G.nTR;
   for (int stride : {1, 2, 7, 512}) {
     std::vector<int> seen(ntiles, 0);

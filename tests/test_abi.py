@@ -67,10 +67,11 @@ def test_workspace_sizes():
     paired = 64  # STM_SGM_PAIRED
     assert lib.stm_sgm_workspace_bytes(H, W, D, 1, paired) == (H + ckpt) * D * 4
     # A single pair at D = 128 takes the tiles fed by walks (needs no device to decide): header +
-    # mailboxes + 6 / 8 floats of border states per element each for row and column lines.
+    # mailboxes + row-segment flags + 6 / 8 floats of border states per element each for row and
+    # column lines.
     assert lib.stm_sgm_form(H, W, D, 1, 0) == 2 and lib.stm_sgm_form(H, W, 64, 1, 0) == 0
     assert lib.stm_sgm_form(H, W, D, 1, paired) == 0 and lib.stm_sgm_form(H, W, D, 1, 512) == 2
     nTR, nTC, strips = (H + 7) // 8, (W + 7) // 8, (W + 63) // 64
-    tiled = (64 + 2 * strips * 2 * 4 * D * 2 + 6 * nTR * W * D + 6 * nTC * H * D) * 4
+    tiled = (64 + 2 * strips * 2 * 4 * D * 2 + (nTR * 4 + 3) // 4 * 4 + 6 * nTR * W * D + 6 * nTC * H * D) * 4
     assert lib.stm_sgm_workspace_bytes(H, W, D, 1, 512) == tiled
     assert lib.stm_sgm_workspace_bytes(H, W, D, 1, 0) == max(tiled, 256 + (H + ckpt) * D * 4)
