@@ -69,6 +69,12 @@ __global__ __launch_bounds__(2 * kT * 64, VPL >= 4 ? 4 : 8) void sgm_tile_kernel
   };
   bool valid;
   if (rows) {
+    // Every unit, the first included, is taken by ticket: a unit is only ever held by a workgroup
+    // that runs, so a segment never waits for one that has not started (wait_flag).
+    if (threadIdx.x == 0) s_unit = (int)atomicAdd(reinterpret_cast<unsigned *>(ws + P.status_off) + kTicketWord, 1u);
+    __syncthreads();
+    id = s_unit;
+    __syncthreads();
     valid = id < nunits;
     unit_first(valid ? id : 0, cur_t);
   } else {
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(2 * kT * 64, VPL >= 4 ? 4 : 8) void sgm_tile_kernel
           }
         }
         if (last_of_unit && w16 == 0 && lane == 0)
-          s_unit = (int)atomicAdd(reinterpret_cast<unsigned *>(ws + P.status_off) + kTicketWord, 1u) + stride;
+          s_unit = (int)atomicAdd(reinterpret_cast<unsigned *>(ws + P.status_off) + kTicketWord, 1u);
       }
       // (the previous tile's winner-takes-all has read the sum tile: both groups are past B4)
       if (P.accumulate) stage_accumulate_row<VPL>(St, out, G, x0, y0, tw, th, w, d0);

@@ -434,7 +434,8 @@ struct TileUnitWalk {
 // the order "all first segments, all second segments, ...".  A segment that is not the first of
 // its row starts from the state its left neighbour left in the column border states and waits
 // for that neighbour's flag; the neighbour's ticket is lower, so it is held by a workgroup that
-// is running or done, and first segments wait for nobody: no residency requirement, no deadlock.
+// is running or done (every unit is taken by ticket, a workgroup's first one too), and first
+// segments wait for nobody: no residency requirement, no deadlock.
 struct RowSegs {
   int len, nseg;  // tiles per segment, segments per row (the last one may be shorter)
 };
