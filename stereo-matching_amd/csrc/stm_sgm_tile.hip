@@ -171,6 +171,10 @@ __global__ __launch_bounds__(2 * kT * 64, VPL >= 4 ? 4 : 8) void sgm_tile_kernel
       lds_barrier();  // B0
       STM_STAMP(2);
       const int next_unit = last_of_unit ? s_unit : 0;
+      // (pair 2's entry states are requested before pair 0: a load from HBM takes as long as a pair)
+      const PhaseGeom g2 = tile_geom(2, w, tw, th);
+      Entries<VPL, 2> E2;
+      load_entries<VPL, 2>(E2, g2, border_base(ws, G, b), G, x0, y0, d0);
       tile_pair<VPL, 0, FINAL>(tile_geom(0, w, tw, th), E0now, full, Ct, St, Ip, P, x0, y0, out, disp, X, lane,
                                [] {}, rows ? &carry : nullptr);
       have_carry = rows && tw == kT && !last_of_unit;
@@ -184,9 +188,6 @@ __global__ __launch_bounds__(2 * kT * 64, VPL >= 4 ? 4 : 8) void sgm_tile_kernel
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (before B1, behind which the flag is set)
       }
       STM_STAMP(3);
-      const PhaseGeom g2 = tile_geom(2, w, tw, th);
-      Entries<VPL, 2> E2;
-      load_entries<VPL, 2>(E2, g2, border_base(ws, G, b), G, x0, y0, d0);
       lds_barrier();  // B1
       if (hand_over && w16 == 0 && lane == 0)
         __hip_atomic_store(flags + seg_flag_index(G, b, cur_t.trow, cur_t.seg), 1u, __ATOMIC_RELEASE,
@@ -234,14 +235,14 @@ __global__ __launch_bounds__(2 * kT * 64, VPL >= 4 ? 4 : 8) void sgm_tile_kernel
       lds_barrier();  // B0
       STM_STAMP(2);
       const int next_unit = last_of_unit ? s_unit : 0;
+      const PhaseGeom g3 = tile_geom(3, w, tw, th);
+      Entries<VPL, 3> E3;
+      load_entries<VPL, 3>(E3, g3, border_base(ws, G, b), G, x0, y0, d0);
       tile_pair<VPL, 1, FINAL>(tile_geom(1, w, tw, th), E1now, full, Ct, St, Ip, P, x0, y0, out, disp, X, lane,
                                [&] {
                                  STM_STAMP(3);
                                  lds_barrier();  // B1
                                });
-      const PhaseGeom g3 = tile_geom(3, w, tw, th);
-      Entries<VPL, 3> E3;
-      load_entries<VPL, 3>(E3, g3, border_base(ws, G, b), G, x0, y0, d0);
       STM_STAMP(4);
       lds_barrier();  // B2
       const bool more = advance(next_unit);

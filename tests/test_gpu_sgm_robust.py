@@ -262,3 +262,24 @@ def test_tiled_forms_fall_back_where_they_do_not_apply(device, oracle):
         got = sgm(_gpu(C, device), _gpu(image, device))
         assert sgm.status() == 0 and not sgm._last_tiled
         assert_same_bits(got.cpu().numpy(), want, "D = 512, form=" + form)
+
+
+def test_bench_starts_its_own_ranks(device):
+    """`python bench.py --gpus 2` without a launcher's environment starts two ranks itself (children
+    under torch.distributed.run; here gloo, both on the one GPU of the box) and prints exactly one
+    JSON line on stdout with n_gpus = 2, both workloads, the parity gates of all ranks passed and
+    the aggregation's status word clear."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "--shared-device", "--steps", "1", "--warmup", "1", "--batch", "4", "--also-batch", "1",
+                          "--also-steps", "1"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "exactly one line on stdout, got %d:\n%s" % (len(lines), out.stdout[-1000:])
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["unit"] == "pairs/s" and line["sgm_status"] == 0
+    assert line["config"]["pairs_per_gpu_per_step"] == 4 and line["value"] > 0
+    assert line["also"]["n_gpus"] == 2 and line["also"]["value"] > 0
+    assert "roofline" in line and line["cpu_baseline"] is None  # (the CPU baseline is a rank-0, N = 1 item)
