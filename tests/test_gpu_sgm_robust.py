@@ -38,7 +38,7 @@ def _raw_sgm(lib, native, C, I, out, flags, fused_disp=None, ws_slack=0):
 
 @pytest.mark.parametrize("H,W,D", [(20, 22, 64), (40, 90, 128), (90, 40, 128), (35, 50, 256), (17, 15, 64),
                                    (33, 129, 128), (64, 80, 128)])
-@pytest.mark.parametrize("form", ["tiled", "paired"])
+@pytest.mark.parametrize("form", ["tiled", "walks", "paired"])
 def test_accumulate_matches_reference_semantics(device, oracle, H, W, D, form):
     """STM_SGM_ACCUMULATE: out = (((out0 + L>) + L<) + ...) on top of the caller's contents
     (the reference's `+=` into its output tensor), in both forms, sum and fused reduction."""
@@ -50,7 +50,7 @@ def test_accumulate_matches_reference_semantics(device, oracle, H, W, D, form):
     init = (rng.random((H, W, D)) * 40).astype(np.float32)
     want = oracle.sgm(C, image, 0.5, 3.0, out=init)
     flags = _native.STM_SGM_ACCUMULATE | _native.STM_SGM_FORMS[form]
-    assert lib.stm_sgm_uses_tiles(H, W, D, 1, flags) == (1 if form == "tiled" else 0)
+    assert lib.stm_sgm_uses_tiles(H, W, D, 1, flags) == (0 if form == "paired" else 1)
     Cg, Ig = _gpu(C, device), _gpu(image, device)
     out = _gpu(init, device)
     _raw_sgm(lib, _native, Cg, Ig, out, flags)
@@ -123,6 +123,30 @@ def test_tiled_pipeline_can_be_captured_into_a_graph(device, oracle):
     for b in range(B):
         l, r = pairs[B + b]
         assert_same_bits(out[b].cpu().numpy(), oracle.wta(oracle.sgm(oracle.ssd(l, r, D), l)), "graph replay %d" % b)
+
+
+def test_single_pair_default_pipeline_can_be_captured_into_a_graph(device, oracle):
+    """The reference's call shape with the defaults (D = 128: tiles fed by walks) inside a captured
+    graph, replayed on a new pair."""
+    import stereomatch
+    H, W, D = 64, 88, 128
+    pipe = stereomatch.Pipeline(stereomatch.cost.SSD(D), stereomatch.disparity_reduce.WinnerTakesAll(),
+                                stereomatch.aggregation.Semiglobal())
+    l0, r0 = oracle.synthetic_pair(H, W, seed=1)
+    l1, r1 = oracle.synthetic_pair(H, W, seed=2)
+    L, R = torch.from_numpy(l0).to(device), torch.from_numpy(r0).to(device)
+    pipe.estimate(L, R)
+    torch.cuda.synchronize()
+    assert pipe.aggregation._last_form == 2
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = pipe.estimate(L, R)
+    L.copy_(torch.from_numpy(l1))
+    R.copy_(torch.from_numpy(r1))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert pipe.status() == 0
+    assert_same_bits(out.cpu().numpy(), oracle.wta(oracle.sgm(oracle.ssd(l1, r1, D), l1)), "graph replay, walks form")
 
 
 def _two_stream_case(device, form, **kw):
