@@ -265,12 +265,17 @@ __device__ __forceinline__ Row<VPL> buf_load_row(BufRsrc r, int voff, int soff) 
   if constexpr (VPL == 4) {
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     const v4u q = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-    o.v[0] = __builtin_bit_cast(float, q.x); o.v[1] = __builtin_bit_cast(float, q.y);
-    o.v[2] = __builtin_bit_cast(float, q.z); o.v[3] = __builtin_bit_cast(float, q.w);
+    // (Elements go through scalars: __builtin_bit_cast applied to a vector ELEMENT expression,
+    // `__builtin_bit_cast(float, q.y)`, reads element 0 with this hipcc -- every lane then holds
+    // x, x, x, x and the load is narrowed to one dword.)
+    const unsigned q0 = q.x, q1 = q.y, q2 = q.z, q3 = q.w;
+    o.v[0] = __builtin_bit_cast(float, q0); o.v[1] = __builtin_bit_cast(float, q1);
+    o.v[2] = __builtin_bit_cast(float, q2); o.v[3] = __builtin_bit_cast(float, q3);
   } else if constexpr (VPL == 2) {
     typedef unsigned v2u __attribute__((ext_vector_type(2)));
     const v2u q = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-    o.v[0] = __builtin_bit_cast(float, q.x); o.v[1] = __builtin_bit_cast(float, q.y);
+    const unsigned q0 = q.x, q1 = q.y;
+    o.v[0] = __builtin_bit_cast(float, q0); o.v[1] = __builtin_bit_cast(float, q1);
   } else {
     static_assert(VPL == 1, "whole 4-, 8- or 16-byte rows per lane");
     o.v[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));

@@ -36,6 +36,8 @@
 // dp_forward_kernel: one wave per image row; lane l holds disparities l*VPL .. l*VPL+VPL-1.
 // Bound: HBM by bytes (4 read + 1 written per (pixel, d)); in practice the forward pass is
 // latency-bound by its dependent chain.
+#include <stdlib.h>
+
 #include "stm_common.h"
 
 namespace stm {
@@ -186,24 +188,34 @@ __global__ __launch_bounds__(kDpBlock) void dp_forward_kernel(const float *__res
 // ---------------------------------------------------------------------------------
 // Value of the lane to the left within the DPP row of 16 (row_ror:1).  Every lane has a
 // source, so there is no "old" value to preserve: one v_mov_b32_dpp, no copy in front of it.
+template <int R>
 __device__ __forceinline__ float rot1(float x) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x121, 0xf,
-                                                            0xf, false));
+  constexpr int ctrl = R == 16 ? 0x121 : 0x13C;  // row_ror:1 / wave_ror:1
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), ctrl, 0xf, 0xf, false));
 }
 
 // G: blocks whose cost pieces are fetched together, G * O * 4 = 128 bytes (one line) for
 // O <= 16 when D is a multiple of 32 (G = 1: a piece per block, as above).  Pieces of 64 bytes
 // and less, a kilobyte apart, are what the batch throughput hit at ~3 TB/s.
-template <int O, int G>
+//
+// R: lanes per image row.  16 (a DPP row, four image rows per wave) is the form described
+// above.  64 (the whole wave on one image row, rotation by wave_ror:1) has R * O >= D with a
+// quarter of the O, i.e. a quarter of the dependent steps per row and four times the waves: what
+// a call with few rows wants (one 1080p pair is 270 waves of the 16-lane form, one per CU, each
+// issuing its ~890 k instructions alone).  Pieces, parking and path runs are the same.
+template <int O, int G, int R = 16, int NS = 2>
 __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ vol_all,
                                                      int8_t *__restrict__ path_all,
                                                      float *__restrict__ rowfin_all,
                                                      const DpShape S) {
-  constexpr int P = 16 * O;
+  static_assert(R == 16 || R == 64, "a DPP row or the whole wave");
+  constexpr int RW = 64 / R;         // image rows per wave
+  constexpr int LR = R == 16 ? 4 : 6;  // log2(R)
+  constexpr int P = R * O;
   constexpr int LP = O / 4;          // load instructions per fetch; dwords of path bytes per block
   constexpr int LPG = G * O / 4;     // lanes per cost piece (16 bytes each)
   constexpr int PPI = 64 / LPG;      // pieces per cooperative load instruction
-  constexpr int NGC = 16 / G;        // pieces per column
+  constexpr int NGC = R / G;         // pieces per column (= piece-starting lanes per image row and block)
   constexpr int LD = G * O + 1;      // padded LDS row: conflict-free ds_read_b32 by 64 lanes
   // G = 1: two buffers (this block's pieces / the next block's).  G > 1: a lane's piece lasts G
   // blocks and its successor is parked at the end of the block that consumes its last part,
@@ -215,20 +227,21 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
   // D = 256) made the LDS the limit on resident workgroups: four per CU; with runs it is
   // nine, which is what the kernel's throughput on a batch follows.
   constexpr int FL = O <= 16 ? 64 / O : 16;  // blocks per run
-  constexpr int PB = FL * LP + (FL == 16 ? 4 : 1);
+  static_assert(FL <= R && LP >= 1, "runs are whole blocks of one column");
+  constexpr int PB = FL * LP + (O >= 32 ? 4 : 1);
   __shared__ __attribute__((aligned(16))) unsigned pbuf[64 * PB];
   // Column 0's initial costs (read in blocks 0-15) and the last column's final costs (written
-  // from block W - 1 on) share their storage: the host takes this kernel only for W >= 17.  The
+  // from block W - 1 on) share their storage: the host takes this kernel only for W >= R + 1.  The
   // 4 KB this saves at D = 256 is what lets five workgroups instead of four share a CU's LDS
   // (30 of 160 KB each) -- the kernel's throughput at batch size is set by that number.
-  __shared__ float initfin[4][P + 1];
-  float (&init)[4][P + 1] = initfin;
-  float (&fin)[4][P + 1] = initfin;
+  __shared__ float initfin[RW][P + 1];
+  float (&init)[RW][P + 1] = initfin;
+  float (&fin)[RW][P + 1] = initfin;
   const int lane = threadIdx.x;
-  const int rq = lane >> 4, v = lane & 15;
+  const int rq = lane >> LR, v = lane & (R - 1);
   const int b = blockIdx.y;
   const int D = S.D, W = S.W, H = S.H;
-  const int row = blockIdx.x * 4 + rq;
+  const int row = blockIdx.x * RW + rq;
   const bool rowok = row < H;
   const size_t npix = (size_t)H * W;
   const float *vol = vol_all + (size_t)b * npix * D;
@@ -236,7 +249,7 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
   const float inf = __builtin_inff();
 
   // Column 0: previous-cost initialisation (Q11a: the reference reads cost[d][row][0]).
-  for (int d = v; d < D; d += 16) {
+  for (int d = v; d < D; d += R) {
     float x = 0.0f;
     if (rowok) x = S.mode == STM_DP_REFERENCE ? vol[((size_t)d * W + row) * D] : vol[((size_t)row * W) * D + d];
     init[rq][d] = x;
@@ -247,23 +260,38 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
   // the G * O disparities from chunk T - v of their column walk (O disparities down the
   // column per block, 16 blocks per column, then the column 16 to the right).  Instruction u,
   // lane i serves the (u * PPI + i / LPG)-th of those 64 / G pieces, 16-byte part i % LPG.
-  // Pieces without work read as +inf, which turns into +inf outputs without a select in the
-  // dependent chain.
+  // Pieces without work read as zeros (out-of-range buffer loads); what their lanes compute
+  // from them is read by lanes without work only (a lane's left neighbour starts earlier and
+  // ends later than it does, and chunks past D - 1 are cut off by the c3 rule below).
+  // Pieces and path runs go through buffer descriptors over this wave's image rows: a 32-bit
+  // offset per lane, and an access without work is one with an out-of-range offset, which the
+  // hardware drops -- no branch around a load or a store, so the compiler can count what is in
+  // flight and a block waits for the pieces it parks only (with a branch it drained everything,
+  // s_waitcnt vmcnt(0), the request of the same block included).
+  typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+  typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+  constexpr unsigned kNowhere = 0x7fffffffu;
+  const int row0 = blockIdx.x * RW;
+  const unsigned rows_here = (unsigned)(H - row0 < RW ? H - row0 : RW);
+  const BufRsrc crs = make_rsrc(vol + (size_t)row0 * W * D, rows_here * (unsigned)(W * D) * 4u);
+  const BufRsrc prs = make_rsrc(path + (size_t)row0 * W * D, rows_here * (unsigned)(W * D));
   int T = 0;
   auto fetch = [&](float4 (&regs)[LP]) {
     const int set = T & (G - 1), n = T / G;
 #pragma unroll
     for (int u = 0; u < LP; ++u) {
       const int j = u * PPI + lane / LPG, part = lane % LPG;
-      const int prow = blockIdx.x * 4 + j / NGC, jj = j % NGC;
+      const int pr = j / NGC, jj = j % NGC;  // image row of the wave, lane group
       const int pv = G * jj + set;
       const int k = n - jj;                       // the piece's index in its lane's walk
-      const int col = pv + 16 * (k / NGC);        // (k >= 0 where it matters)
+      const int col = pv + R * (k / NGC);         // (k >= 0 where it matters)
       const int pd0 = G * O * (k % NGC);
-      const bool ok = k >= 0 && col < W && pd0 < D && prow < H;
-      const size_t at = ((size_t)(ok ? prow : 0) * W + (ok ? col : 0)) * D + (ok ? pd0 : 0) + 4 * part;
-      const float4 x = *reinterpret_cast<const float4 *>(vol + at);
-      regs[u] = ok ? x : make_float4(inf, inf, inf, inf);
+      const bool ok = (k >= 0) & (col < W) & (pd0 < D) & (row0 + pr < H);
+      const unsigned at = ok ? 4u * (unsigned)((pr * W + col) * D + pd0 + 4 * part) : kNowhere;
+      const v4u_t x = __builtin_amdgcn_raw_buffer_load_b128(crs, at, 0, 0);
+      const unsigned x0 = x.x, x1 = x.y, x2 = x.z, x3 = x.w;  // (bit_cast of a vector element: see buf_load_row)
+      regs[u] = make_float4(__builtin_bit_cast(float, x0), __builtin_bit_cast(float, x1),
+                            __builtin_bit_cast(float, x2), __builtin_bit_cast(float, x3));
     }
     ++T;
   };
@@ -273,7 +301,7 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
 #pragma unroll
     for (int u = 0; u < LP; ++u) {
       const int j = u * PPI + lane / LPG, part = lane % LPG;
-      const int pi = (j / NGC) * 16 + G * (j % NGC) + set;  // the lane that owns the piece
+      const int pi = (j / NGC) * R + G * (j % NGC) + set;   // the lane that owns the piece
       float *dst = &tile[buf][pi * LD + 4 * part];
       dst[0] = regs[u].x; dst[1] = regs[u].y; dst[2] = regs[u].z; dst[3] = regs[u].w;
     }
@@ -287,26 +315,29 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
   // while those of block blk + 2 are requested into the other -- a block takes about a
   // microsecond, a load from HBM up to two or three, and with one block of lead every block of
   // a lone workgroup (a single pair: one per CU) waited for its loads.
-  float4 regs_a[LP], regs_b[LP];
-  fetch(regs_a);
-  park(0, regs_a, 0);
-  fetch(regs_b);
+  // (NS register sets, NS - 1 blocks of lead: the whole-wave form's blocks are a third as long.)
+  static_assert(NS >= 2, "one set is parked while the others are in flight");
+  float4 regs[NS][LP];
+  fetch(regs[0]);
+  park(0, regs[0], 0);
+#pragma unroll
+  for (int i = 1; i < NS; ++i) fetch(regs[i]);
   wave_lds_handoff();  // init[] and tile[0] are read by other lanes below
   float hist[O];
 #pragma unroll
   for (int j = 0; j < O; ++j) hist[j] = inf;
   float prev = inf;
-  const int nblocks = W + 15;
+  const int nblocks = W + R - 1;
   auto block = [&](int blk, float4 (&freg)[LP], const float4 (&preg)[LP]) {
     const int cur = blk & 1;
-    fetch(freg);  // the pieces of block blk + 2: in flight while this and the next block compute
+    fetch(freg);  // the pieces of block blk + NS: in flight while this and the next NS - 1 blocks compute
     const int q = blk - v;
-    const int col = v + 16 * (q >> 4);
-    const int d0 = O * (q & 15);
+    const int col = v + R * (q >> LR);
+    const int d0 = O * (q & (R - 1));
     const bool live = q >= 0 && col < W && d0 < D && rowok;
     // The block's O cost values move from LDS to registers up front, so the dependent
-    // chain below has no memory waits.  Lanes without work get +inf costs, which makes
-    // their outputs +inf without a select in the chain.
+    // chain below has no memory waits.  Lanes without work get zero costs (see fetch): no
+    // select in the chain, and nothing with work reads what they put out.
     float cst[O], outs[O];
 #pragma unroll
     for (int j = 0; j < O; ++j) cst[j] = tile[G == 1 ? cur : 0][lane * LD + (q & (G - 1)) * O + j];
@@ -314,7 +345,7 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
 #pragma unroll
     for (int u = 0; u < LP; ++u) pk[u] = 0;
     const bool col0 = live && col == 0;
-    if (blk < 16) {
+    if (blk < R) {
       // Column 0 is in flight (wave-uniform test): its "update" is the initial cost with
       // direction 0, so these blocks carry one extra select per step.
 #pragma unroll
@@ -325,12 +356,12 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
         const float c1 = d > 0 ? prev : inf;
         const float m23 = c2 < c3 ? c2 : c3;
         const float m = c1 < m23 ? c1 : m23;
-        const float out = col0 ? init[rq][d < P ? d : 0] : cst[j] + m;  // +inf when not live
+        const float out = col0 ? init[rq][d < P ? d : 0] : cst[j] + m;
         const int dir = col0 ? 0 : (c1 < m23 ? -1 : (c2 < c3 ? 0 : 1));
         prev = out;
         outs[j] = out;
         pk[j / 4] |= (unsigned)(dir & 0xff) << (8 * (j % 4));
-        hist[j] = rot1(out);        // row_ror:1 -> the column on the right
+        hist[j] = rot1<R>(out);        // row_ror:1 -> the column on the right
       }
     } else {
       // Steady state.  With m23 = (c2 < c3 ? c2 : c3) the reference's three-way choice is
@@ -349,12 +380,12 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
         const int dir = c1 < m23 ? -1 : (c2 < c3 ? 0 : 1);
         outs[j] = out;
         pk[j / 4] |= (unsigned)(dir & 0xff) << (8 * (j % 4));
-        hist[j] = rot1(out);
+        hist[j] = rot1<R>(out);
         c1 = out;
       }
       prev = c1;
     }
-    if (blk >= nblocks - 16) {  // wave-uniform: the last column is in flight
+    if (blk >= nblocks - R) {  // wave-uniform: the last column is in flight
       // Final costs of the row: the lane that owns the last column parks them in LDS.
       const bool isfin = live && col == W - 1;
 #pragma unroll
@@ -375,36 +406,43 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
       // image row; lane v serves the (v / FL)-th of them, piece v % FL of its run.
       const int vd = ((blk + 1) & (FL - 1)) + FL * (v / FL);
       const int qd = blk - vd;                 // = FL - 1 (mod FL)
-      const int cd = vd + 16 * (qd >> 4);      // that lane's column (negative before the first one)
-      const int chunk = (qd & 15) - (FL - 1) + (v % FL);  // the piece's O disparities
-      const int crow = blockIdx.x * 4 + rq;    // this lane serves image row rq
-      const unsigned *src = &pbuf[(rq * 16 + vd) * PB + (v % FL) * LP];
+      const int cd = vd + R * (qd >> LR);      // that lane's column (negative before the first one)
+      const int chunk = (qd & (R - 1)) - (FL - 1) + (v % FL);  // the piece's O disparities
+      const unsigned *src = &pbuf[(rq * R + vd) * PB + (v % FL) * LP];
       unsigned out_w[LP];
 #pragma unroll
       for (int u = 0; u < LP; ++u) out_w[u] = src[u];
-      if (qd >= 0 && cd < W && crow < H && chunk * O < D) {
-        int8_t *dst = path + ((size_t)crow * W + cd) * D + chunk * O;
+      const bool okd = (qd >= 0) & (cd < W) & (row0 + rq < H) & (chunk * O < D);  // (this lane serves image row rq)
+      const unsigned dst = okd ? (unsigned)((rq * W + cd) * D + chunk * O) : kNowhere;
 #pragma unroll
-        for (int u = 0; u < LP; u += 4) {
-          if (LP >= 4) {
-            *reinterpret_cast<uint4 *>(dst + 4 * u) = make_uint4(out_w[u], out_w[(u + 1) % LP], out_w[(u + 2) % LP], out_w[(u + 3) % LP]);
-          } else {
-            *reinterpret_cast<uint2 *>(dst) = make_uint2(out_w[0], out_w[1 % LP]);
-          }
+      for (int u = 0; u < LP; u += 4) {
+        if constexpr (LP >= 4) {
+          v4u_t w4;
+          w4.x = out_w[u]; w4.y = out_w[(u + 1) % LP]; w4.z = out_w[(u + 2) % LP]; w4.w = out_w[(u + 3) % LP];
+          __builtin_amdgcn_raw_buffer_store_b128(w4, prs, dst, 4 * u, 0);
+        } else if constexpr (LP == 2) {
+          v2u_t w2;
+          w2.x = out_w[0]; w2.y = out_w[1 % LP];
+          __builtin_amdgcn_raw_buffer_store_b64(w2, prs, dst, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b32(out_w[0], prs, dst, 0, 0);
         }
       }
     }
     park(G == 1 ? cur ^ 1 : 0, preg, blk + 1);
     wave_lds_handoff();  // the parked pieces (and pbuf) change hands between iterations
   };
-  for (int blk = 0; blk < nblocks; blk += 2) {
-    block(blk, regs_a, regs_b);
-    if (blk + 1 < nblocks) block(blk + 1, regs_b, regs_a);
+  for (int blk = 0; blk < nblocks; blk += NS) {
+    // (Whole groups of NS blocks, without a test between them: blocks past the last one find no
+    // lane with work -- every column is >= W -- and the compiler can only count the loads and
+    // stores in flight, i.e. wait for exactly the set a block parks, on straight-line code.)
+#pragma unroll
+    for (int i = 0; i < NS; ++i) block(blk + i, regs[i], regs[(i + 1) % NS]);
   }
   // Flush the final costs (fin[] was written by the lanes that own the last column).
   float *rowfin = rowfin_all + ((size_t)b * H + (rowok ? row : 0)) * D;
   if (rowok)
-    for (int d = v; d < D; d += 16) rowfin[d] = fin[rq][d];
+    for (int d = v; d < D; d += R) rowfin[d] = fin[rq][d];
 }
 
 // Q11b: path[r][c][0] = 0 for r < D, r < c < H (and c < W, implied by H <= W).
@@ -544,6 +582,29 @@ __global__ __launch_bounds__(64) void dp_backtrack_window_kernel(const int8_t *_
   }
 }
 
+// Whether a call takes the whole-wave form of the forward pass (tools/dp_scale.py): it has a
+// quarter of the narrow form's dependent steps per wave on four times the waves and ~1.3x its
+// instructions in total, so it wins while the narrow form leaves SIMDs without a wave -- one
+// 1080p x 256 pair: 270 narrow waves on 1,024 SIMDs, 1.57 -> 1.00 ms; two 720p x 192 pairs
+// 1.07 -> 0.68 ms; one or two Teddy pairs 0.26 -> 0.24 ms; from ~1.5 narrow waves per CU on the
+// two take the same time and the narrow one is ahead on batches (16 x 1080p: 0.71 against 0.74 ms
+// per pair; 16 Teddy pairs 0.033 against 0.045).  Above D = 256 the narrow form's O = 32 / 64
+// blocks do not fit the register file (spills) and the whole-wave form is 2-3x faster at every
+// batch size (1030 x 1040 x 1024: 6.2 -> 1.9 ms, four pairs 15.3 -> 6.0 ms).
+bool dp_prefers_wide(int H, int D, int batch) {
+  if (D > 256) return true;
+  static int cus_of[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  int cus = dev >= 0 && dev < 16 ? cus_of[dev] : 0;
+  if (cus == 0) {
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    if (dev >= 0 && dev < 16) cus_of[dev] = cus;
+  }
+  const long long narrow_waves = (long long)batch * ((H + 3) / 4);
+  return narrow_waves * 2 <= (long long)cus * 3;
+}
+
 }  // namespace
 }  // namespace stm
 
@@ -573,14 +634,27 @@ extern "C" int stm_dp_f32(const float *volume, int8_t *path, float *row_final, i
   const uintptr_t align = VPL >= 4 ? 15 : (VPL == 2 ? 7 : 3);
   const bool vec = (D == VPL * 64) && ((reinterpret_cast<uintptr_t>(volume) & align) == 0) &&
                    ((reinterpret_cast<uintptr_t>(path) & 3) == 0);
-  // Wavefront form: whole O-disparity chunks (O = 8, 16, 32, 64 for D <= 128, 256, 512, 1024),
+  // Wavefront forms: whole O-disparity chunks (narrow: O = 8, 16, 32, 64 for D <= 128, 256, 512, 1024),
   // 16-byte-aligned cost rows and at least 17 columns (dp_tile_kernel's shared initial / final
   // cost buffer); everything else takes the fixed-point form.
   int O = 8;
   while (16 * O < D) O <<= 1;
+  // (and four image rows of costs within the 2 GiB a 32-bit buffer offset is computed in)
   const bool wavefront = (D % O == 0) && W >= 17 && ((reinterpret_cast<uintptr_t>(volume) & 15) == 0) &&
-                         ((reinterpret_cast<uintptr_t>(path) & 15) == 0);
-  if (wavefront) {
+                         ((reinterpret_cast<uintptr_t>(path) & 15) == 0) && (long long)W * D < (1ll << 27);
+  // The whole-wave form (one image row per wave, O = 4 / 8 / 16 for D <= 256 / 512 / 1024): a
+  // quarter of the dependent steps per row on four times the waves.
+  int O64 = 4;
+  while (64 * O64 < D) O64 <<= 1;
+  const bool wide_ok = wavefront && D % 32 == 0 && D % O64 == 0 && W >= 65;
+  bool wide = wide_ok && dp_prefers_wide(H, D, batch);
+  if (const char *e = getenv("STM_DP_LANES")) wide = wide_ok && atoi(e) == 64;  // (A/B measurements)
+  if (wide) {
+    const dim3 wgrid(H, batch), wblock(64);
+    if (O64 == 4) hipLaunchKernelGGL((dp_tile_kernel<4, 8, 64, 4>), wgrid, wblock, 0, s, volume, path, row_final, S);
+    else if (O64 == 8) hipLaunchKernelGGL((dp_tile_kernel<8, 4, 64>), wgrid, wblock, 0, s, volume, path, row_final, S);
+    else hipLaunchKernelGGL((dp_tile_kernel<16, 2, 64>), wgrid, wblock, 0, s, volume, path, row_final, S);
+  } else if (wavefront) {
     const dim3 wgrid((H + 3) / 4, batch), wblock(64);
     const bool lines = D % 32 == 0;  // whole 128-byte pieces
     if (O == 8 && lines) hipLaunchKernelGGL((dp_tile_kernel<8, 4>), wgrid, wblock, 0, s, volume, path, row_final, S);

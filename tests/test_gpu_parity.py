@@ -606,6 +606,40 @@ def test_dp_wide_tiles(device, oracle, H, W, D, mode):
     assert np.array_equal(gpath, wpath), "dp path volume"
 
 
+@pytest.mark.parametrize("lanes", ["16", "64", None])
+@pytest.mark.parametrize("B,H,W,D,mode", [
+    (1, 65, 65, 64, "reference"),     # the whole-wave form's narrowest image (W = 65), D < its period of 256
+    (2, 33, 131, 96, "corrected"),    # D not a power of two, rows not a multiple of four, a batch
+    (1, 260, 300, 256, "reference"),  # every chunk of the period in use; the Q11a/b quirks
+    (3, 5, 200, 128, "corrected"),    # three columns per lane and a bit
+    (1, 1, 97, 32, "corrected"),      # one row, one line of disparities
+    (1, 40, 130, 512, "corrected"),   # O = 8 on the whole wave
+])
+def test_dp_forward_forms(device, oracle, monkeypatch, lanes, B, H, W, D, mode):
+    """The forward pass's two wavefront forms (a DPP row of 16 lanes per image row, four rows per
+    wave / the whole wave on one row -- picked by the number of rows in the call, forced here
+    through STM_DP_LANES) give the same path volume, final costs and disparities bit for bit."""
+    import stereomatch
+    if lanes is None:
+        monkeypatch.delenv("STM_DP_LANES", raising=False)
+    else:
+        monkeypatch.setenv("STM_DP_LANES", lanes)
+    rng = np.random.default_rng(B * 7 + H + W + D)
+    vols = [_random_volume(rng, H, W, D, kind) for kind in ("float", "ties", "inf")[:B]]
+    while len(vols) < B:
+        vols.append(_random_volume(rng, H, W, D, "float"))
+    dp = stereomatch.disparity_reduce.DynamicProgramming(mode=mode)
+    got = dp(_gpu(np.stack(vols) if B > 1 else vols[0], device))
+    for b, vol in enumerate(vols):
+        want, wpath, wfin = oracle.dp(vol, mode=1 if mode == "corrected" else 0, return_aux=True)
+        g = got[b] if B > 1 else got
+        gp = dp.path_volume[b] if B > 1 else dp.path_volume
+        gf = dp.row_final_costs[b] if B > 1 else dp.row_final_costs
+        assert_same_bits(gf.cpu().numpy(), wfin, "dp row_final (pair %d)" % b)
+        assert np.array_equal(gp.cpu().numpy(), wpath), "dp path volume (pair %d)" % b
+        assert_same_bits(g.cpu().numpy(), want, "dp disparity (pair %d)" % b)
+
+
 @pytest.mark.parametrize("H,W", [(14, 31), (31, 14)])
 def test_batched_sgm_with_rewalked_diagonals(device, oracle, H, W):
     """Wide and tall images in a batch: every pair has its own spill rows and checkpoints."""
