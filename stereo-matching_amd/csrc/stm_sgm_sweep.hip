@@ -6,6 +6,8 @@
 // 8 x 8 tile are kept (border states), nothing is added into a sum here.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "stm_sgm_tiled_dev.h"
 
 namespace stm {
@@ -228,6 +230,7 @@ __device__ __forceinline__ void sweep_image(const float *__restrict__ cost_all, 
   // recomputing 64-bit addresses every row is row time; at D = 256 the sweep is HBM-bound and
   // the two loops take the same time.
   if constexpr (H2) {
+    constexpr int PFH0 = 2;
     if (active) {
       static_assert(!H2 || CW == 4, "two columns per half-wave");
       // ---- D = 128: lanes 0-31 own columns xa, xa + 1, lanes 32-63 columns xa + 2, xa + 3, four
@@ -240,7 +243,7 @@ __device__ __forceinline__ void sweep_image(const float *__restrict__ cost_all, 
       const bool edge = !(xa >= 1 && xa + CW <= W - 1);
       const int half = lane >> 5, hl = lane & 31, dh = hl * 4;
       const int vw = 2 * wv + half;
-      constexpr int PFH = 2;  // cost rows in flight beyond the current one
+      constexpr int PFH = PFH0;  // cost rows in flight beyond the current one
       // Addresses are a wave-uniform base plus this lane's 32-bit offset (its half's first
       // column and its disparities).
       const unsigned loff = (unsigned)(half * 2 * D + dh);
@@ -271,7 +274,6 @@ __device__ __forceinline__ void sweep_image(const float *__restrict__ cost_all, 
       const int y_first = UP ? H - 1 : 0;
       float *colA = colA_here && xa + 3 < W ? colb_ptr(ws, G, b, UP ? 2 : 1, (xa + 3) >> 3, y_first) : nullptr;
       float *colB = colB_here ? colb_ptr(ws, G, b, UP ? 5 : 4, xa >> 3, y_first) : nullptr;
-      const int col_step = UP ? -colb_row_stride(G) : colb_row_stride(G);
       float *rowV = rowb_ptr(ws, G, b, UP ? 3 : 0, 0, xa);  // line 0; line t is t * rowb_line_stride further
       const long long kstride = rowb_dir_stride(G);
       const float p1v = in_vgpr(P.p1);
@@ -285,97 +287,164 @@ __device__ __forceinline__ void sweep_image(const float *__restrict__ cost_all, 
       const unsigned my_off = (unsigned)(vw * D + dh);
       const unsigned inA_off = (unsigned)((vw > 0 ? vw - 1 : 0) * D + dh);
       const unsigned inB_off = (unsigned)(kAB + (vw < NV - 1 ? vw + 1 : NV - 1) * D + dh);
-      // A wave at a strip edge reads one mailbox: A from the left (wave 0) or B from the right
-      // (last wave); both only in a one-wave strip, which the sweeps never have.
-      const u64 *sub = !left_lds ? subA : (!right_lds ? subB : nullptr);
-      auto leave = [&](int par, unsigned t) {  // what leaves the half: A of its last column, B of its first
-        if (pubA && half == 1) mbox_publish<4>(pubA, D, dh, t, Ah[1]);
-        if (pubB && half == 0) mbox_publish<4>(pubB, D, dh, t, Bh[0]);
-        store_row<4, true>(xbase + par * kPar + my_off, 0, D, 0, Ah[1]);
-        store_row<4, true>(xbase + par * kPar + kAB + my_off, 0, D, 0, Bh[0]);
+      // Mailbox role of the wave: 0 none (interior waves, and edge waves at an image border),
+      // 1 first wave of a strip with a neighbour on the left (publishes B of its first column
+      // from half 0, takes A for it), 2 last wave with a neighbour on the right (publishes A of
+      // its last column from half 1, takes B).  Both only in a one-wave strip, which the sweeps
+      // never have.  The row loop is instantiated per role so that what a wave issues to memory
+      // per row is the same on (nearly) every path through the row: a load or store under a
+      // wave-uniform condition is a branch around it, behind which hipcc no longer knows how
+      // many accesses are in flight and waits for ALL of them at the row's first use of a cost
+      // row (s_waitcnt vmcnt(0): the two rows of prefetch included, once per row; 51 % of the
+      // sweep's time was VALU work, 63 % waiting).  Column-line stores go through buffer
+      // descriptors for the same reason: the half with nothing to store stores out of range.
+      const int role = (pubB && subA) ? 1 : ((pubA && subB) ? 2 : 0);
+      constexpr unsigned kNowhere = 0x7fffffffu;
+      // A column line's rows from row 0 on (colA / colB point at row y_first; no line: an empty
+      // range); the row in flight is the scalar part of the address.  (Two stores rather than one
+      // with selected operands: a select between Ah[1] and Bh[0] sends both arrays to scratch.)
+      const BufRsrc colA_rs = make_rsrc(colA ? colA - (long long)y_first * colb_row_stride(G) : ws, colA ? colb_line_bytes(G) : 0u);
+      const BufRsrc colB_rs = make_rsrc(colB ? colB - (long long)y_first * colb_row_stride(G) : ws, colB ? colb_line_bytes(G) : 0u);
+      // (Per-lane offsets of the conditional accesses are formed where they are used, from a
+      // laundered copy of the lane's half: hoisted out of the row loop each of them is a register
+      // the loop does not have -- it runs at the 128 a 16-wave workgroup can have.)
+      auto my_half = [&]() {
+        unsigned h = (unsigned)half;
+        asm volatile("" : "+v"(h));
+        return h;
       };
+      auto run = [&](auto role_tag) {
+        constexpr int ROLE = decltype(role_tag)::value;
+        const u64 *sub = ROLE == 1 ? subA : subB;  // (ROLE != 0)
+        u64 *pub = ROLE == 1 ? pubB : pubA;
+        const BufRsrc pub_rs = make_rsrc(ROLE != 0 ? (const void *)pub : (const void *)ws, ROLE != 0 ? mbox_bytes(D) : 0u);
+        const BufRsrc sub_rs = make_rsrc(ROLE != 0 ? (const void *)sub : (const void *)ws, ROLE != 0 ? mbox_bytes(D) : 0u);
+        auto leave = [&](int par, unsigned t) {  // what leaves the half: A of its last column, B of its first
+          if constexpr (ROLE != 0) {
+            const Row<4> &x = ROLE == 2 ? Ah[1] : Bh[0];
+            const unsigned tag = t + 1;
+            const unsigned soff = mbox_slot_byte(D, t);
+            // (Under the lane's condition, not with an out-of-range offset for the other half:
+            // with the latter, runs took rows whose tags matched and whose values were another
+            // column's -- a write-through store's out-of-range lanes are not simply dropped.)
+            if (half == (ROLE == 2 ? 1 : 0)) {
+#pragma unroll
+              for (int j = 0; j < 4; j += 2) {
+                v4u_t q;
+                q.x = __builtin_bit_cast(unsigned, x.v[j]); q.y = tag;
+                q.z = __builtin_bit_cast(unsigned, x.v[j + 1]); q.w = tag;
+                __builtin_amdgcn_raw_buffer_store_b128(q, pub_rs, (unsigned)dh * 8u, soff + (unsigned)j * 8u, kAuxSc1);
+              }
+            }
+          }
+          store_row<4, true>(xbase + par * kPar + my_off, 0, D, 0, Ah[1]);
+          store_row<4, true>(xbase + par * kPar + kAB + my_off, 0, D, 0, Bh[0]);
+        };
+        auto peek = [&](unsigned t) {  // requests the neighbour's row t (looked at a row later)
+          if constexpr (ROLE != 0) {
+            const unsigned soff = mbox_slot_byte(D, t);
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+              const v4u_t g = __builtin_amdgcn_raw_buffer_load_b128(sub_rs, (unsigned)dh * 8u, soff + (unsigned)j * 8u, kAuxSc1);
+              qa4.val[j] = g.x; qa4.tag[j] = g.y;
+              qa4.val[j + 1] = g.z; qa4.tag[j + 1] = g.w;
+            }
+          }
+        };
 
 #pragma unroll
-      for (int u = 0; u <= PFH; ++u) refill(ch[u], ich[u], iph[u]);
-      int y = y_first;
-      for (int t0 = 0; t0 < H; t0 += PFH + 1) {
+        for (int u = 0; u <= PFH; ++u) refill(ch[u], ich[u], iph[u]);
+        // Whole groups of PFH + 1 rows, every wave of the sweep alike (sweep_rows_run): the rows
+        // past the last one step on the last row's costs again, exchange and publish like any
+        // other (their neighbours run them too) and store nothing -- a test `t < H` around a
+        // row is one more join at which the count of accesses in flight is lost.
+        int y = y_first;
+        for (int t0 = 0; t0 < sweep_rows_run(H, PFH); t0 += PFH + 1) {
 #pragma unroll
-        for (int u = 0; u <= PFH; ++u) {
-          const int t = t0 + u;
-          if (t < H) {
-            const int par = t & 1;
-            const float pen = sgm_penalty(ich[u], iph[u], P.p1, P.p2);
-            if (t == 0) {
+          for (int u = 0; u <= PFH; ++u) {
+            const int t = t0 + u;
+            const bool real = t < H;
+            {
+              const int par = t & 1;
+              const float pen = sgm_penalty(ich[u], iph[u], P.p1, P.p2);
+              if (t == 0) {
 #pragma unroll
-              for (int j = 0; j < 2; ++j) { Vh[j] = ch[u][j]; Ah[j] = ch[u][j]; Bh[j] = ch[u][j]; }
-              leave(par, 0u);
-            } else {
-              {  // V in column 0, A into column 1 (from column 0), B into column 0 (from column 1)
-                Row<4> st[3] = {Vh[0], Ah[0], Bh[1]};
-                const Row<4> cc[3] = {ch[u][0], ch[u][1], ch[u][0]};
-                sgm_step_h2x3<0, 4, 2>(st, cc, pen, p1v, below, above, drop_tail);
-                Vh[0] = st[0];
-                Ah[1] = st[1];
-                Bh[0] = st[2];
-                if (edge) Bh[0] = pick_row(start_b0, ch[u][0], Bh[0]);
-              }
-              leave(par, (unsigned)t);
-              {  // V in column 1, A into column 0 and B into column 1 from what arrived
-                Row<4> st[3];
-                st[0] = Vh[1];
-                st[1] = load_row<4, true>(xbase + (par ^ 1) * kPar + inA_off, 0, D, 0);
-                st[2] = load_row<4, true>(xbase + (par ^ 1) * kPar + inB_off, 0, D, 0);
-                if (sub) {
-                  Row<4> r;
-                  if (dead || !mbox_take<4>(qa4, (unsigned)(t - 1), r))
-                    mbox_wait<4>(sub, D, dh, (unsigned)(t - 1), r, dead, status);
-                  if (!left_lds) {  // wave 0 of a strip: its first half takes A from the strip on the left
-                    if (half == 0) st[1] = r;
-                  } else {          // last wave: its second half takes B from the strip on the right
-                    if (half == 1) st[2] = r;
+                for (int j = 0; j < 2; ++j) { Vh[j] = ch[u][j]; Ah[j] = ch[u][j]; Bh[j] = ch[u][j]; }
+                leave(par, 0u);
+              } else {
+                {  // V in column 0, A into column 1 (from column 0), B into column 0 (from column 1)
+                  Row<4> st[3] = {Vh[0], Ah[0], Bh[1]};
+                  const Row<4> cc[3] = {ch[u][0], ch[u][1], ch[u][0]};
+                  sgm_step_h2x3<0, 4, 2>(st, cc, pen, p1v, below, above, drop_tail);
+                  Vh[0] = st[0];
+                  Ah[1] = st[1];
+                  Bh[0] = st[2];
+                  if (edge) Bh[0] = pick_row(start_b0, ch[u][0], Bh[0]);
+                }
+                leave(par, (unsigned)t);
+                {  // V in column 1, A into column 0 and B into column 1 from what arrived
+                  Row<4> st[3];
+                  st[0] = Vh[1];
+                  st[1] = load_row<4, true>(xbase + (par ^ 1) * kPar + inA_off, 0, D, 0);
+                  st[2] = load_row<4, true>(xbase + (par ^ 1) * kPar + inB_off, 0, D, 0);
+                  if constexpr (ROLE != 0) {
+                    Row<4> r;
+                    // Everything this wave has in flight lands before the granules are looked
+                    // at: with the counted wait hipcc puts here, runs took a row whose tags
+                    // matched and whose values did not (the write-through granule loads seem not
+                    // to return in order with the wave's other traffic).  Mid-row the rows in
+                    // flight were requested half a row ago and more, so the drain is cheap.
+                    if (dead || !mbox_take<4>(qa4, (unsigned)(t - 1), r))
+                      mbox_wait<4>(sub, D, dh, (unsigned)(t - 1), r, dead, status);
+                    if constexpr (ROLE == 1) {  // its first half takes A from the strip on the left
+                      if (half == 0) st[1] = r;
+                    } else {                    // its second half takes B from the strip on the right
+                      if (half == 1) st[2] = r;
+                    }
+                  }
+                  const Row<4> cc[3] = {ch[u][1], ch[u][0], ch[u][1]};
+                  sgm_step_h2x3<3, 1, 5>(st, cc, pen, p1v, below, above, drop_tail);
+                  Vh[1] = st[0];
+                  Ah[0] = st[1];
+                  Bh[1] = st[2];
+                  if (edge) {
+                    Ah[0] = pick_row(start_a0, ch[u][0], Ah[0]);
+                    Bh[1] = pick_row(start_b1, ch[u][1], Bh[1]);
                   }
                 }
-                const Row<4> cc[3] = {ch[u][1], ch[u][0], ch[u][1]};
-                sgm_step_h2x3<3, 1, 5>(st, cc, pen, p1v, below, above, drop_tail);
-                Vh[1] = st[0];
-                Ah[0] = st[1];
-                Bh[1] = st[2];
-                if (edge) {
-                  Ah[0] = pick_row(start_a0, ch[u][0], Ah[0]);
-                  Bh[1] = pick_row(start_b1, ch[u][1], Bh[1]);
-                }
               }
-            }
-            if (sub && !dead && t + 1 < H) mbox_peek<4>(sub, D, dh, (unsigned)t, qa4);
-            if (sweep_stores_row(UP, y)) {
-              float *r0 = rowV + (long long)(y >> 3) * rowb_line_stride(G);
+              peek((unsigned)t);
+              if (real && sweep_stores_row(UP, y)) {
+                float *r0 = rowV + (long long)(y >> 3) * rowb_line_stride(G);
 #pragma unroll
-              for (int j = 0; j < 2; ++j) {
-                if (!edge || (j == 0 ? valid0 : valid1)) {
-                  store_row<4, true, true>(r0 + (loff + (unsigned)(j * D)), 0, D, 0, Vh[j]);
-                  store_row<4, true, true>(r0 + kstride + (loff + (unsigned)(j * D)), 0, D, 0, Ah[j]);
-                  store_row<4, true, true>(r0 + 2 * kstride + (loff + (unsigned)(j * D)), 0, D, 0, Bh[j]);
+                for (int j = 0; j < 2; ++j) {
+                  if (!edge || (j == 0 ? valid0 : valid1)) {
+                    store_row<4, true, true>(r0 + (loff + (unsigned)(j * D)), 0, D, 0, Vh[j]);
+                    store_row<4, true, true>(r0 + kstride + (loff + (unsigned)(j * D)), 0, D, 0, Ah[j]);
+                    store_row<4, true, true>(r0 + 2 * kstride + (loff + (unsigned)(j * D)), 0, D, 0, Bh[j]);
+                  }
                 }
               }
+              {  // the column lines of this wave (A where x % 8 == 7, B where x % 8 == 0), row y
+                const int soff = real ? (int)colb_line_row_byte(G, y) : 0;
+                const unsigned h = my_half();
+                buf_store_row<4>(colA_rs, (int)(real && h == 1 ? (unsigned)dh * 4u : kNowhere), soff, Ah[1]);
+                buf_store_row<4>(colB_rs, (int)(real && h == 0 ? (unsigned)dh * 4u : kNowhere), soff, Bh[0]);
+              }
+              y += UP ? -1 : 1;
+              refill(ch[u], ich[u], iph[u]);
+              lds_barrier();
             }
-            if (colA) {
-              if (half == 1) store_row<4, true, true>(colA + (unsigned)dh, 0, D, 0, Ah[1]);
-              colA += col_step;
-            }
-            if (colB) {
-              if (half == 0) store_row<4, true, true>(colB + (unsigned)dh, 0, D, 0, Bh[0]);
-              colB += col_step;
-            }
-            y += UP ? -1 : 1;
-            refill(ch[u], ich[u], iph[u]);
-            lds_barrier();
           }
         }
-      }
+      };
+      if (role == 0) run(std::integral_constant<int, 0>{});
+      else if (role == 1) run(std::integral_constant<int, 1>{});
+      else run(std::integral_constant<int, 2>{});
       return;
     }
     // (a wave past the image only keeps the row barriers)
-    for (int t = 0; t < H; ++t) lds_barrier();
+    for (int t = 0; t < sweep_rows_run(H, PFH0); ++t) lds_barrier();
     return;
   } else if (VPL <= 2 && xa >= 1 && xa + CW <= W - 1) {
     SweepCursor rows;  // the next row to fetch

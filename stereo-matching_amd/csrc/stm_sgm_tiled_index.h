@@ -94,6 +94,10 @@ STM_HD long long colb_off(const TiledGeom &G, int b, int k, int tc, int y) {
 STM_HD long long rowb_line_stride(const TiledGeom &G) { return (long long)G.W * G.D; }
 STM_HD long long rowb_dir_stride(const TiledGeom &G) { return (long long)G.nTR * G.W * G.D; }
 STM_HD int colb_row_stride(const TiledGeom &G) { return G.D; }
+// One column line (direction k, tile column tc: colb_off(G, b, k, tc, 0) onwards) in bytes, and
+// the byte at which image row y begins in it (buffer descriptor over the line).
+STM_HD unsigned colb_line_bytes(const TiledGeom &G) { return (unsigned)(G.H * colb_row_stride(G)) * 4u; }
+STM_HD unsigned colb_line_row_byte(const TiledGeom &G, int y) { return (unsigned)(y * colb_row_stride(G)) * 4u; }
 // The same inside an image's block (32-bit; make_geom has checked that they fit).
 STM_HD unsigned rowb_in_image(const TiledGeom &G, int k, int t, int x) {
   return (unsigned)(((k * G.nTR + t) * G.W + x) * G.D);
@@ -126,6 +130,9 @@ STM_HD long long mbox_granule_off(const TiledGeom &G, int sweep, int b, int stri
 }
 STM_HD long long mbox_granules(const TiledGeom &G) { return 2ll * G.batch * G.strips * 2 * kMboxSlots * G.D; }
 STM_HD int mbox_slot_granule(int D, unsigned row) { return (int)(row % kMboxSlots) * D; }
+// The same in bytes, for a buffer descriptor over ONE mailbox (base: its first granule).
+STM_HD unsigned mbox_bytes(int D) { return (unsigned)(kMboxSlots * D) * 8u; }
+STM_HD unsigned mbox_slot_byte(int D, unsigned row) { return (unsigned)mbox_slot_granule(D, row) * 8u; }
 
 // ---- row sweeps -------------------------------------------------------------------------------
 // Image row of sweep step t (the up sweep runs from the last row).
@@ -185,6 +192,10 @@ struct SweepCursor {
     ++t_next;
   }
 };
+
+// Rows a D = 128 sweep steps through: whole groups of pf + 1 (its loop has no test between the
+// rows of a group; rows >= H step on the last row's costs again and store nothing).
+STM_HD int sweep_rows_run(int H, int pf) { return (H + pf) / (pf + 1) * (pf + 1); }
 
 // Border-state rows of a sweep: line index and the float offset of column x in it.
 STM_HD bool sweep_stores_row(bool up, int y) { return (y & (kT - 1)) == (up ? 0 : kT - 1); }

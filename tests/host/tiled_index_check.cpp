@@ -90,6 +90,21 @@ static void check_sweeps(const TiledGeom &G, const Ext &E) {
           }
           for (unsigned row = 0; row < (unsigned)H; ++row)
             if (row < 8 || row + 8 > (unsigned)H) in_range(mbox_slot_granule(D, row), D, (long long)kMboxSlots * D, "mailbox slot");
+          // D = 128: descriptors over one mailbox, a row's slot as a byte offset, the rows of
+          // the whole groups the loop runs (those past H - 1 publish and poll like any other)
+          if (VPL == 2) {
+            const int run = sweep_rows_run(H, PF);
+            CHECK(run >= H && run < H + PF + 1 && run % (PF + 1) == 0, "whole groups of rows: %d for H=%d", run, H);
+            CHECK(mbox_bytes(D) == (unsigned)(kMboxSlots * D) * 8u, "mailbox bytes");
+            for (unsigned row = 0; row < (unsigned)run; ++row) {
+              if (!(row < 8 || row + 8 > (unsigned)H)) continue;
+              CHECK(mbox_slot_byte(D, row) == (unsigned)mbox_slot_granule(D, row) * 8u, "slot byte");
+              // lane: granules dh .. dh + 3 (dh = 4 * (lane & 31)), two 16-byte accesses
+              for (int hl = 0; hl < 32; ++hl)
+                for (int j = 0; j < 4; j += 2)
+                  in_range((long long)mbox_slot_byte(D, row) + (unsigned)(hl * 4) * 8u + (unsigned)j * 8u, 16, mbox_bytes(D), "mailbox access (bytes)");
+            }
+          }
           // generic loop: fetch(t) for t = 0 .. H - 1 + PF + 1
           for (int t = 0; t <= H + PF; ++t) {
             for (int j = 0; j < CW; ++j) in_range(sweep_cost_in_image(G, up, t, xa + j), D, E.cost, "generic cost fetch");
@@ -180,6 +195,17 @@ static void check_sweeps(const TiledGeom &G, const Ext &E) {
                 if (xa + j >= W) continue;  // (h2 edge waves: predicated; interior waves: all valid)
                 for (int kk = 0; kk < 3; ++kk)
                   check_rowb(G, b, (up ? 3 : 0) + kk, y >> 3, xa + j, r0 + kk * rowb_dir_stride(G) + (long long)j * D, "interior row border store");
+              }
+            }
+            if (h2) {  // the column lines as buffer descriptors: base = the line's row 0, the row as a byte offset
+              for (int side = 0; side < 2; ++side) {
+                const long long at = side == 0 ? colA : colB;
+                if (at < 0) continue;
+                const long long line0 = (side == 0 ? colb_off(G, b, up ? 2 : 1, (xa + 3) >> 3, y_first) : colb_off(G, b, up ? 5 : 4, xa >> 3, y_first))
+                                        - (long long)y_first * colb_row_stride(G);
+                CHECK(line0 == (side == 0 ? colb_off(G, b, up ? 2 : 1, (xa + 3) >> 3, 0) : colb_off(G, b, up ? 5 : 4, xa >> 3, 0)), "line base is its row 0");
+                CHECK(colb_line_row_byte(G, y) + (unsigned)D * 4u <= colb_line_bytes(G), "row %d inside the line's descriptor", y);
+                CHECK(line0 + colb_line_row_byte(G, y) / 4 == at, "descriptor address of row %d equals the running pointer", y);
               }
             }
             if (colA >= 0) {
