@@ -51,6 +51,15 @@ __global__ __launch_bounds__(256) void sgm_hwalk_kernel(const float *__restrict_
   Row<VPL> prev = cbuf[0];
   const int keep = left ? 0 : kT - 1;
   const int k = left ? 3 : 0;
+  // The states leave through a buffer descriptor over this row's slots of the direction's
+  // column lines; a step that keeps nothing stores out of range, which the hardware drops, and
+  // the steps run in whole groups of PF (past the row's end: the last column's costs again,
+  // nothing stored).  With `if (keeps) store` and `if (i < W)` every step ended in a join at
+  // which hipcc no longer knows how many accesses are in flight: it waited for ALL of them
+  // (s_waitcnt vmcnt(0)) right behind each step's load, i.e. a wave had one cost row in flight
+  // instead of PF and the walk ran at the rate Little's law gives 32 waves per CU.
+  constexpr unsigned kNowhere = 0x7fffffffu;
+  const BufRsrc brs = make_rsrc(colb_ptr(ws, G, b, k, 0, y), colb_walk_bytes(G));
   for (int base = 0; base < W; base += PF) {
     if ((base & (kWave - 1)) == 0) {
       pen = sgm_penalty(na, nb, P.p1, P.p2);
@@ -59,13 +68,12 @@ __global__ __launch_bounds__(256) void sgm_hwalk_kernel(const float *__restrict_
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int i = base + u;
-      if (i < W) {
-        const Row<VPL> c = cbuf[u];
-        cbuf[u] = load_row<VPL, true, true>(cost, (size_t)col_of(i + PF), D, d0);
-        if (i > 0) prev = sgm_step<VPL, true>(prev, c, read_lane(pen, i & (kWave - 1)), X);
-        const int x = col_of(i);
-        if ((x & (kT - 1)) == keep) store_row<VPL, true, true>(colb_ptr(ws, G, b, k, x >> 3, y), 0, D, d0, prev);
-      }
+      const Row<VPL> c = cbuf[u];
+      cbuf[u] = load_row<VPL, true, true>(cost, (size_t)col_of(i + PF), D, d0);
+      if (i > 0) prev = sgm_step<VPL, true>(prev, c, read_lane(pen, i & (kWave - 1)), X);
+      const int x = col_of(i);
+      const bool keeps = i < W && (x & (kT - 1)) == keep;
+      buf_store_row<VPL>(brs, (int)(keeps ? (unsigned)d0 * 4u : kNowhere), (int)colb_walk_tc_byte(G, x >> 3), prev);
     }
   }
 }

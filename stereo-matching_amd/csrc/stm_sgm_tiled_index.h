@@ -98,6 +98,11 @@ STM_HD int colb_row_stride(const TiledGeom &G) { return G.D; }
 // the byte at which image row y begins in it (buffer descriptor over the line).
 STM_HD unsigned colb_line_bytes(const TiledGeom &G) { return (unsigned)(G.H * colb_row_stride(G)) * 4u; }
 STM_HD unsigned colb_line_row_byte(const TiledGeom &G, int y) { return (unsigned)(y * colb_row_stride(G)) * 4u; }
+// The states one image row y keeps in direction k's column lines, one per tile column
+// (colb_off(G, b, k, 0, y) onwards, a line apart): the byte at which tile column tc's begins and
+// the bytes up to the end of the last one (buffer descriptor of a horizontal walk).
+STM_HD unsigned colb_walk_tc_byte(const TiledGeom &G, int tc) { return (unsigned)(tc * G.H * G.D) * 4u; }
+STM_HD unsigned colb_walk_bytes(const TiledGeom &G) { return colb_walk_tc_byte(G, G.nTC - 1) + (unsigned)G.D * 4u; }
 // The same inside an image's block (32-bit; make_geom has checked that they fit).
 STM_HD unsigned rowb_in_image(const TiledGeom &G, int k, int t, int x) {
   return (unsigned)(((k * G.nTR + t) * G.W + x) * G.D);
