@@ -282,6 +282,20 @@ __device__ __forceinline__ Row<VPL> buf_load_row(BufRsrc r, int voff, int soff) 
   }
   return o;
 }
+// A buffer store reads its data registers for some cycles after it has issued, and a VALU write to
+// them in the very next slots races with that read.  hipcc's hazard recognizer pads the case
+// only when the store's soffset is an immediate: with an SGPR there it assumes the issue takes
+// long enough, which does not hold on gfx950 -- a 16-byte store followed at once by the next
+// row's arithmetic in the same registers wrote that arithmetic's values to memory for the last
+// lanes (found as mailbox rows whose tags matched and whose values did not, and as column-line
+// states holding intensity differences).  After every buffer store with a register soffset: two
+// wait states during which the data registers are still in use as far as the compiler knows.
+template <int VPL>
+__device__ __forceinline__ void hold_store_data(const Row<VPL> &x) {
+  if constexpr (VPL == 4) asm volatile("s_nop 1" ::"v"(x.v[0]), "v"(x.v[1]), "v"(x.v[2]), "v"(x.v[3]) : "memory");
+  else if constexpr (VPL == 2) asm volatile("s_nop 1" ::"v"(x.v[0]), "v"(x.v[1]) : "memory");
+  else asm volatile("s_nop 1" ::"v"(x.v[0]) : "memory");
+}
 template <int VPL>
 __device__ __forceinline__ void buf_store_row(BufRsrc r, int voff, int soff, const Row<VPL> &x) {
   if constexpr (VPL == 4) {
@@ -299,6 +313,7 @@ __device__ __forceinline__ void buf_store_row(BufRsrc r, int voff, int soff, con
     static_assert(VPL == 1, "whole 4-, 8- or 16-byte rows per lane");
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x.v[0]), r, voff, soff, 0);
   }
+  hold_store_data<VPL>(x);
 }
 
 // Loads / stores of data that another workgroup of the SAME launch has written / will read:

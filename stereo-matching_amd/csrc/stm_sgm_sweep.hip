@@ -324,9 +324,6 @@ __device__ __forceinline__ void sweep_image(const float *__restrict__ cost_all, 
             const Row<4> &x = ROLE == 2 ? Ah[1] : Bh[0];
             const unsigned tag = t + 1;
             const unsigned soff = mbox_slot_byte(D, t);
-            // (Under the lane's condition, not with an out-of-range offset for the other half:
-            // with the latter, runs took rows whose tags matched and whose values were another
-            // column's -- a write-through store's out-of-range lanes are not simply dropped.)
             if (half == (ROLE == 2 ? 1 : 0)) {
 #pragma unroll
               for (int j = 0; j < 4; j += 2) {
@@ -334,6 +331,7 @@ __device__ __forceinline__ void sweep_image(const float *__restrict__ cost_all, 
                 q.x = __builtin_bit_cast(unsigned, x.v[j]); q.y = tag;
                 q.z = __builtin_bit_cast(unsigned, x.v[j + 1]); q.w = tag;
                 __builtin_amdgcn_raw_buffer_store_b128(q, pub_rs, (unsigned)dh * 8u, soff + (unsigned)j * 8u, kAuxSc1);
+                asm volatile("s_nop 1" ::"v"(q) : "memory");  // (hold_store_data: the store is still reading q)
               }
             }
           }
@@ -354,20 +352,20 @@ __device__ __forceinline__ void sweep_image(const float *__restrict__ cost_all, 
 
 #pragma unroll
         for (int u = 0; u <= PFH; ++u) refill(ch[u], ich[u], iph[u]);
-        // Whole groups of PFH + 1 rows, every wave of the sweep alike (sweep_rows_run): the rows
-        // past the last one step on the last row's costs again, exchange and publish like any
-        // other (their neighbours run them too) and store nothing -- a test `t < H` around a
-        // row is one more join at which the count of accesses in flight is lost.
+        // Row 0, then whole groups of PFH + 1 rows, every wave of the sweep alike
+        // (sweep_rows_run): the rows past the last one step on the last row's costs again,
+        // exchange and publish like any other (their neighbours run them too) and store nothing
+        // -- a test `t < H` (or `t == 0`) around a row is one more join at which the count of
+        // accesses in flight is lost.
         int y = y_first;
-        for (int t0 = 0; t0 < sweep_rows_run(H, PFH); t0 += PFH + 1) {
-#pragma unroll
-          for (int u = 0; u <= PFH; ++u) {
-            const int t = t0 + u;
+        auto row = [&](const int t, auto u_tag, auto first_tag) {
+            constexpr int u = decltype(u_tag)::value;
+            constexpr bool FIRST = decltype(first_tag)::value;
             const bool real = t < H;
             {
               const int par = t & 1;
               const float pen = sgm_penalty(ich[u], iph[u], P.p1, P.p2);
-              if (t == 0) {
+              if constexpr (FIRST) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) { Vh[j] = ch[u][j]; Ah[j] = ch[u][j]; Bh[j] = ch[u][j]; }
                 leave(par, 0u);
@@ -389,11 +387,6 @@ __device__ __forceinline__ void sweep_image(const float *__restrict__ cost_all, 
                   st[2] = load_row<4, true>(xbase + (par ^ 1) * kPar + inB_off, 0, D, 0);
                   if constexpr (ROLE != 0) {
                     Row<4> r;
-                    // Everything this wave has in flight lands before the granules are looked
-                    // at: with the counted wait hipcc puts here, runs took a row whose tags
-                    // matched and whose values did not (the write-through granule loads seem not
-                    // to return in order with the wave's other traffic).  Mid-row the rows in
-                    // flight were requested half a row ago and more, so the drain is cheap.
                     if (dead || !mbox_take<4>(qa4, (unsigned)(t - 1), r))
                       mbox_wait<4>(sub, D, dh, (unsigned)(t - 1), r, dead, status);
                     if constexpr (ROLE == 1) {  // its first half takes A from the strip on the left
@@ -435,7 +428,13 @@ __device__ __forceinline__ void sweep_image(const float *__restrict__ cost_all, 
               refill(ch[u], ich[u], iph[u]);
               lds_barrier();
             }
-          }
+        };
+        static_assert(PFH == 2, "the rows of a group name their register set");
+        row(0, std::integral_constant<int, 0>{}, std::true_type{});
+        for (int t0 = 1; t0 < sweep_rows_run(H, PFH); t0 += PFH + 1) {
+          row(t0, std::integral_constant<int, 1>{}, std::false_type{});
+          row(t0 + 1, std::integral_constant<int, 2>{}, std::false_type{});
+          row(t0 + 2, std::integral_constant<int, 0>{}, std::false_type{});
         }
       };
       if (role == 0) run(std::integral_constant<int, 0>{});

@@ -198,9 +198,9 @@ struct SweepCursor {
   }
 };
 
-// Rows a D = 128 sweep steps through: whole groups of pf + 1 (its loop has no test between the
-// rows of a group; rows >= H step on the last row's costs again and store nothing).
-STM_HD int sweep_rows_run(int H, int pf) { return (H + pf) / (pf + 1) * (pf + 1); }
+// Rows a D = 128 sweep steps through: row 0, then whole groups of pf + 1 (its loop has no test
+// between the rows of a group; rows >= H step on the last row's costs again and store nothing).
+STM_HD int sweep_rows_run(int H, int pf) { return 1 + (H - 1 + pf) / (pf + 1) * (pf + 1); }
 
 // Border-state rows of a sweep: line index and the float offset of column x in it.
 STM_HD bool sweep_stores_row(bool up, int y) { return (y & (kT - 1)) == (up ? 0 : kT - 1); }

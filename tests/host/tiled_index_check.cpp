@@ -94,7 +94,7 @@ static void check_sweeps(const TiledGeom &G, const Ext &E) {
           // the whole groups the loop runs (those past H - 1 publish and poll like any other)
           if (VPL == 2) {
             const int run = sweep_rows_run(H, PF);
-            CHECK(run >= H && run < H + PF + 1 && run % (PF + 1) == 0, "whole groups of rows: %d for H=%d", run, H);
+            CHECK(run >= H && run < H + PF + 1 && (run - 1) % (PF + 1) == 0, "row 0 and whole groups of rows: %d for H=%d", run, H);
             CHECK(mbox_bytes(D) == (unsigned)(kMboxSlots * D) * 8u, "mailbox bytes");
             for (unsigned row = 0; row < (unsigned)run; ++row) {
               if (!(row < 8 || row + 8 > (unsigned)H)) continue;

@@ -61,3 +61,47 @@ def test_mailbox_poll_is_reissued_inside_the_wait_loop(tmp_path):
         loads = [l for l in body if re.search(r"(buffer|global)_load_dword", l)]
         assert loads and all(" sc1" in l for l in loads), "no sc1 poll in the loop at line %d:\n%s" % (
             i + 1, "\n".join(body))
+
+
+def _vrange(reg):
+    m = re.match(r"v\[(\d+):(\d+)\]", reg)
+    if m:
+        return int(m.group(1)), int(m.group(2))
+    n = int(reg[1:])
+    return n, n
+
+
+def test_register_soffset_buffer_stores_hold_their_data(tmp_path):
+    """ISA of the kernels that store through buffer descriptors with an SGPR soffset: each such
+    store is followed by the s_nop of hold_store_data (stm_common.h) before anything writes its
+    data registers -- hipcc
+    pads the store-data hazard only for immediate soffsets, and on gfx950 the next VALU write
+    to the data registers otherwise races with the store's read of them."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    for name in ("stm_sgm_sweep.hip", "stm_sgm_hwalk.hip", "stm_dp.hip"):
+        asm = str(tmp_path / (name + ".s"))
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                               "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
+                               "-I", os.path.join(ROOT, "include"), "-I", CSRC, "--cuda-device-only", "-S",
+                               os.path.join(CSRC, name), "-o", asm], stderr=subprocess.DEVNULL)
+        lines = open(asm).read().splitlines()
+        n = 0
+        for i, l in enumerate(lines):
+            m = re.match(r"\s*buffer_store_dword(x[234])?\s+(v\[?\d+[:\d\]]*), v\d+, s\[\d+:\d+\], (s\d+) offen", l)
+            if not m:
+                continue
+            n += 1
+            lo, hi = _vrange(m.group(2))
+            held = False
+            for x in lines[i + 1:i + 120]:  # up to the s_nop: nothing writes the data registers
+                if re.match(r"\s*s_nop\b", x):
+                    held = True
+                    break
+                w = re.match(r"\s*(v_\w+|global_load\w*|buffer_load\w*|scratch_load\w*|ds_read\w*)\s+(v\[\d+:\d+\]|v\d+)\b", x)
+                if w:
+                    a, b = _vrange(w.group(2))
+                    assert b < lo or a > hi, "%s line %d: %s writes the data of %s" % (name, i + 1, x.strip(), l.strip())
+                assert not re.match(r"\s*(s_cbranch|s_branch|s_endpgm)", x), "%s line %d: control flow behind %s before its s_nop" % (name, i + 1, l.strip())
+            assert held, "%s line %d: no s_nop behind %s" % (name, i + 1, l.strip())
+        if name != "stm_dp.hip":
+            assert n > 0, name + ": expected buffer stores with a register soffset"
