@@ -58,6 +58,29 @@ __global__ __launch_bounds__(256) void sgm_hwalk_kernel(const float *__restrict_
   // which hipcc no longer knows how many accesses are in flight: it waited for ALL of them
   // (s_waitcnt vmcnt(0)) right behind each step's load, i.e. a wave had one cost row in flight
   // instead of PF and the walk ran at the rate Little's law gives 32 waves per CU.
+  // (At D = 256 a wave's loads are twice as large, the walk was at the HBM's rate already, and the
+  // dropped 16-byte stores cost more than the counted waits bring: 3.6 against 3.3 ms per eight
+  // 1080p pairs.  There the steps keep their conditions.)
+  if constexpr (VPL == 4) {
+    for (int base = 0; base < W; base += PF) {
+      if ((base & (kWave - 1)) == 0) {
+        pen = sgm_penalty(na, nb, P.p1, P.p2);
+        pen_inputs(base + kWave);
+      }
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int i = base + u;
+        if (i < W) {
+          const Row<VPL> c = cbuf[u];
+          cbuf[u] = load_row<VPL, true, true>(cost, (size_t)col_of(i + PF), D, d0);
+          if (i > 0) prev = sgm_step<VPL, true>(prev, c, read_lane(pen, i & (kWave - 1)), X);
+          const int x = col_of(i);
+          if ((x & (kT - 1)) == keep) store_row<VPL, true, true>(colb_ptr(ws, G, b, k, x >> 3, y), 0, D, d0, prev);
+        }
+      }
+    }
+    return;
+  }
   constexpr unsigned kNowhere = 0x7fffffffu;
   const BufRsrc brs = make_rsrc(colb_ptr(ws, G, b, k, 0, y), colb_walk_bytes(G));
   for (int base = 0; base < W; base += PF) {
