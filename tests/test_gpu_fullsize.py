@@ -124,6 +124,30 @@ def test_1080p_sgm_full_volume_matches_oracle(device, oracle):
     assert float((disp == 7).float().mean()) > 0.9
 
 
+def test_1080p_dynamic_programming_matches_oracle_in_both_forward_forms(device, oracle, monkeypatch):
+    """The DP reduce of one 1080p x 256 volume (the call shape that takes the whole-wave forward
+    pass) against the oracle -- path volume, final costs, disparities -- and the same volume
+    through the narrow form (forced) bit for bit."""
+    import stereomatch
+    H, W, D = 1080, 1920, 256
+    L, R, Lg, Rg = _pair(oracle, H, W, device)
+    C = stereomatch.cost.Birchfield(D)(Lg, Rg)
+    monkeypatch.delenv("STM_DP_LANES", raising=False)
+    dp = stereomatch.disparity_reduce.DynamicProgramming()
+    disp = dp(C)
+    path, fin = dp.path_volume.clone(), dp.row_final_costs.clone()
+    monkeypatch.setenv("STM_DP_LANES", "16")
+    dp16 = stereomatch.disparity_reduce.DynamicProgramming()
+    disp16 = dp16(C)
+    assert torch.equal(disp16, disp) and torch.equal(dp16.path_volume, path)
+    assert torch.equal(dp16.row_final_costs.view(torch.int32), fin.view(torch.int32))
+    del dp16
+    want, wpath, wfin = oracle.dp(C.cpu().numpy(), mode=0, return_aux=True)
+    assert np.array_equal(disp.cpu().numpy(), want)
+    assert np.array_equal(fin.cpu().numpy().view(np.uint32), wfin.view(np.uint32))
+    assert np.array_equal(path.cpu().numpy(), wpath)
+
+
 def test_teddy_batch_takes_the_streaming_variants_and_matches_single_pairs(device, oracle):
     """A four-pair Teddy batch is past the Infinity-Cache threshold, so SSD stores and the
     aggregation's segment loads/stores use their non-temporal variants: every pair must still

@@ -307,3 +307,25 @@ def test_bench_starts_its_own_ranks(device):
     assert line["config"]["pairs_per_gpu_per_step"] == 4 and line["value"] > 0
     assert line["also"]["n_gpus"] == 2 and line["also"]["value"] > 0
     assert "roofline" in line and line["cpu_baseline"] is None  # (the CPU baseline is a rank-0, N = 1 item)
+
+
+@pytest.mark.parametrize("D", [64, 128, 256])
+def test_strip_handoffs_hold_over_repeated_runs(device, D):
+    """The sweep strips hand diagonal states to each other through mailboxes -- a timing-dependent
+    path (round 3 met rows whose tags matched and whose values did not).  Shapes
+    with several strips and several images, each run five times against the paired form
+    (tools/stress_sweeps.py is the long version)."""
+    import stereomatch
+    for (H, W, B) in [(40, 90, 5), (64, 200, 3), (33, 129, 8), (17, 65, 16), (9, 1000, 2), (100, 300, 2)]:
+        g = torch.Generator().manual_seed(H * 1000 + W + D)
+        C = torch.rand((B, H, W, D), generator=g) * 50 + 10
+        C[..., D - 1] = torch.rand((B, H, W), generator=g)
+        C = C.to(device)
+        img = torch.randint(0, 5, (B, H, W), generator=g).float().to(device)
+        ref = stereomatch.aggregation.Semiglobal(form="paired", penalty1=0.5, penalty2=3.0)(C, img)
+        for rep in range(5):
+            sg = stereomatch.aggregation.Semiglobal(form="tiled", penalty1=0.5, penalty2=3.0)
+            out = sg(C, img)
+            assert sg.status() == 0
+            n = int((out.view(torch.int32) != ref.view(torch.int32)).sum())
+            assert n == 0, "%dx%dx%d B=%d run %d: %d entries differ from the paired form" % (H, W, D, B, rep, n)

@@ -11,6 +11,8 @@ reps = int(os.environ.get("REPS", "10"))
 D = int(os.environ.get("D", "128"))
 cases = [(40, 90, 1), (40, 90, 5), (375, 450, 1), (375, 450, 4), (64, 200, 3), (33, 129, 8), (100, 300, 2),
          (17, 65, 16), (200, 131, 3), (9, 1000, 2)]
+if os.environ.get("BIG"):  # a full launch group: 8 strips x 32 images
+    cases.append((375, 450, 32))
 bad = 0; t0 = time.time()
 for (H, W, B) in cases:
     g = torch.Generator().manual_seed(H * 1000 + W)
