@@ -582,6 +582,94 @@ __global__ __launch_bounds__(64) void dp_backtrack_window_kernel(const int8_t *_
   }
 }
 
+// The windowed walk with the next chunk's records requested while this chunk is walked: the
+// window is cut around the disparity at which the path enters the CURRENT chunk, so it must
+// hold what the next chunk can reach from anywhere this one can leave it -- 2 K on either side,
+// kBtWide = 4 K + 16 bytes per column.  1.8x the bytes of the plain windowed walk, which is why
+// only calls with few rows take it: there a chunk is a load's latency plus a serial walk of K
+// dependent LDS reads, and this form overlaps the two (one 1080p x 256 pair: 0.22 -> 0.13 ms).
+constexpr int kBtWide = 4 * kBtK + 16;  // 144
+
+__global__ __launch_bounds__(64) void dp_backtrack_ahead_kernel(const int8_t *__restrict__ path_all,
+                                                                const float *__restrict__ rowfin_all,
+                                                                int32_t *__restrict__ disp_all,
+                                                                const DpShape S) {
+  __shared__ __attribute__((aligned(16))) int8_t tile[2][kBtK * kBtWide];
+  __shared__ int dchunk[kBtK];
+  const int lane = threadIdx.x;
+  const int row = blockIdx.x;
+  const int b = blockIdx.y;
+  const int D = S.D, W = S.W;
+  const int8_t *path = path_all + (((size_t)b * S.H + row) * W) * D;
+  const float *rf = rowfin_all + ((size_t)b * S.H + row) * D;
+  int32_t *disp = disp_all + ((size_t)b * S.H + row) * W;
+
+  // First minimum of the row's final costs (torch::argmin semantics for non-NaN input).
+  float best = __builtin_inff();
+  int idx = 0x7fffffff;
+  for (int d = lane; d < D; d += 64) {
+    const float q = rf[d];
+    if (idx == 0x7fffffff) idx = d;
+    if (q < best) { best = q; idx = d; }
+  }
+  const float m = group_min_f32<64>(best);
+  int cand = (best == m) ? idx : 0x7fffffff;
+  int cur = group_min_i32<64>(cand);
+  if (cur == 0x7fffffff) cur = 0;  // all-NaN row
+  if (lane == 0) disp[W - 1] = cur;
+
+  constexpr int kParts = kBtWide / 16;                    // 16-byte parts per column window
+  constexpr int kRegs = (kBtK * kParts + 63) / 64;        // parts per lane and chunk
+  auto window = [&](int c) {                              // of a chunk entered at disparity c (and of its successor)
+    int w = (c - 2 * kBtK) & ~15;                         // (negative: & ~15 rounds down)
+    return w < 0 ? 0 : (w > D - kBtWide ? D - kBtWide : w);
+  };
+  uint4 regs[kRegs];
+  auto request = [&](int hi, int wlo) {                   // the records of columns hi, hi - 1, .. (a chunk)
+    const int lo = hi - kBtK + 1 > 0 ? hi - kBtK + 1 : 0;
+    const int ncol = hi - lo + 1;
+#pragma unroll
+    for (int r = 0; r < kRegs; ++r) {
+      const int i = lane + 64 * r;
+      const int c = i / kParts, part = i - c * kParts;
+      const bool ok = i < ncol * kParts;
+      regs[r] = ok ? *reinterpret_cast<const uint4 *>(path + (size_t)(lo + c) * D + wlo + 16 * part) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto park = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < kRegs; ++r) {
+      const int i = lane + 64 * r;
+      if (i < kBtK * kParts) reinterpret_cast<uint4 *>(tile[buf])[i] = regs[r];
+    }
+  };
+  int wcur = window(cur);
+  request(W - 2, wcur);
+  park(0);
+  __syncthreads();
+  int buf = 0;
+  for (int hi = W - 2; hi >= 0; hi -= kBtK) {
+    const int lo = hi - kBtK + 1 > 0 ? hi - kBtK + 1 : 0;
+    const int ncol = hi - lo + 1;
+    const int wnext = window(cur);  // cut around this chunk's entry: holds the next chunk's reach
+    if (lo > 0) request(lo - 1, wnext);
+    if (lane == 0) {
+      for (int col = hi; col >= lo; --col) {
+        cur = cur + (int)tile[buf][(col - lo) * kBtWide + (cur - wcur)];
+        cur = cur < 0 ? 0 : (cur > D - 1 ? D - 1 : cur);
+        dchunk[col - lo] = cur;
+      }
+    }
+    __syncthreads();
+    cur = __builtin_amdgcn_readfirstlane(cur);
+    if (lane < ncol) disp[lo + lane] = dchunk[lane];
+    if (lo > 0) park(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+    wcur = wnext;
+  }
+}
+
 // Whether a call takes the whole-wave form of the forward pass (tools/dp_scale.py): it has a
 // quarter of the narrow form's dependent steps per wave on four times the waves and ~1.3x its
 // instructions in total, so it wins while the narrow form leaves SIMDs without a wave -- one
@@ -687,7 +775,11 @@ extern "C" int stm_dp_f32(const float *volume, int8_t *path, float *row_final, i
     if (rc != STM_OK) return rc;
   }
   const size_t lds = (size_t)kBtChunk * ((D + 15) & ~15) + sizeof(int) * kBtChunk;
-  if (D % 16 == 0 && D >= kBtWin && (reinterpret_cast<uintptr_t>(path) & 15) == 0)
+  // (The read-ahead form where the rows of the call leave most of the wave slots empty.)
+  const bool few_rows = (long long)H * batch <= 4096;
+  if (D % 16 == 0 && D >= kBtWide && few_rows && (reinterpret_cast<uintptr_t>(path) & 15) == 0)
+    hipLaunchKernelGGL(dp_backtrack_ahead_kernel, dim3(H, batch), dim3(64), 0, s, path, row_final, disparity, S);
+  else if (D % 16 == 0 && D >= kBtWin && (reinterpret_cast<uintptr_t>(path) & 15) == 0)
     hipLaunchKernelGGL(dp_backtrack_window_kernel, dim3(H, batch), dim3(64), 0, s, path, row_final, disparity, S);
   else
     hipLaunchKernelGGL(dp_backtrack_kernel, dim3(H, batch), dim3(64), lds, s, path, row_final, disparity, S);
