@@ -10,9 +10,10 @@ dev = torch.device("cuda:0")
 n, seed0 = int(os.environ.get("N", "40")), int(os.environ.get("SEED", "1000"))
 t0 = time.time(); bad = 0
 for seed in range(seed0, seed0 + n):
-    try:
-        T.test_tiled_fuzz_against_paired(dev, seed)
-    except AssertionError as e:
-        bad += 1
-        print("FAIL seed", seed, str(e)[:300], flush=True)
-print("seeds %d..%d (25 cases each) in %.0f s, failures: %d" % (seed0, seed0 + n - 1, time.time() - t0, bad))
+    for form in ("tiled", "walks"):
+        try:
+            T.test_tiled_fuzz_against_paired(dev, seed, form)
+        except AssertionError as e:
+            bad += 1
+            print("FAIL seed", seed, form, str(e)[:300], flush=True)
+print("seeds %d..%d (25 cases each, two forms) in %.0f s, failures: %d" % (seed0, seed0 + n - 1, time.time() - t0, bad))
