@@ -239,6 +239,19 @@ static void check_hwalk(const TiledGeom &G, const Ext &E) {
         if ((x & (kT - 1)) == kT - 1) check_colb(G, b, 0, x >> 3, y, colb_off(G, b, 0, x >> 3, y), "walk store ->");
         if ((x & (kT - 1)) == 0) check_colb(G, b, 3, x >> 3, y, colb_off(G, b, 3, x >> 3, y), "walk store <-");
       }
+  // D <= 128: the states of one image row leave through a descriptor over the row's slots of
+  // the direction's column lines (base: tile column 0, one line per tile column further).
+  if (G.D <= 128)
+    for (int k = 0; k < 6; k += 3)
+      for (int y = 0; y < G.H; y += (G.H > 3 ? G.H / 3 : 1)) {
+        const long long base = colb_off(G, 0, k, 0, y);
+        CHECK(colb_walk_bytes(G) == colb_walk_tc_byte(G, G.nTC - 1) + (unsigned)G.D * 4u, "walk descriptor size");
+        for (int tc = 0; tc < G.nTC; ++tc) {
+          CHECK(base + colb_walk_tc_byte(G, tc) / 4 == colb_off(G, 0, k, tc, y), "walk descriptor: tile column %d", tc);
+          CHECK(colb_walk_tc_byte(G, tc) + (unsigned)G.D * 4u <= colb_walk_bytes(G), "walk descriptor range");
+        }
+        CHECK((long long)colb_walk_bytes(G) < (1ll << 31), "below the out-of-range marker");
+      }
   (void)E;
 }
 
