@@ -8,7 +8,7 @@ C=$ROOT/stereo-matching_amd/csrc
 make -C $C -j8 2>&1 | grep -E "error|warning:" || true
 mkdir -p $ROOT/tools/_probe /tmp/isa
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -I$ROOT/include -I$C"
-TILED="stm_sgm_tiled stm_sgm_sweep stm_sgm_hwalk stm_sgm_tile stm_sgm_tile_h2"
+TILED="stm_sgm_tiled stm_sgm_sweep stm_sgm_hwalk stm_sgm_bwalk stm_sgm_tile stm_sgm_tile_h2"
 if [ "$1" != "usage" ]; then
   OBJS=""
   for f in $TILED; do
