@@ -192,6 +192,7 @@ int sgm_run_tiled(const float *cost, const float *left, float *out, int32_t *dis
   // the left-to-right direction walked instead of carried.
   c.segs = plan.G.nTC / 16 < 1 ? 1 : (plan.G.nTC / 16 > kMaxSegs ? kMaxSegs : plan.G.nTC / 16);
   if (getenv("STM_TILE_SEGS")) c.segs = atoi(getenv("STM_TILE_SEGS"));  // (development)
+  c.segs = c.segs < 1 ? 1 : (c.segs > kMaxSegs ? kMaxSegs : c.segs);     // (the flag area holds kMaxSegs per tile row)
   if (getenv("STM_TILE_NO_ROWS") && D != 128) c.by_rows = false;        // (development: A/B against the walked form)
   c.status_off = plan.status_off;
   c.group = plan.group;
