@@ -288,13 +288,13 @@ __device__ __forceinline__ Row<VPL> buf_load_row(BufRsrc r, int voff, int soff) 
 // long enough, which does not hold on gfx950 -- a 16-byte store followed at once by the next
 // row's arithmetic in the same registers wrote that arithmetic's values to memory for the last
 // lanes (found as mailbox rows whose tags matched and whose values did not, and as column-line
-// states holding intensity differences).  After every buffer store with a register soffset: two
+// states holding intensity differences).  After every buffer store with a register soffset: four
 // wait states during which the data registers are still in use as far as the compiler knows.
 template <int VPL>
 __device__ __forceinline__ void hold_store_data(const Row<VPL> &x) {
-  if constexpr (VPL == 4) asm volatile("s_nop 1" ::"v"(x.v[0]), "v"(x.v[1]), "v"(x.v[2]), "v"(x.v[3]) : "memory");
-  else if constexpr (VPL == 2) asm volatile("s_nop 1" ::"v"(x.v[0]), "v"(x.v[1]) : "memory");
-  else asm volatile("s_nop 1" ::"v"(x.v[0]) : "memory");
+  if constexpr (VPL == 4) asm volatile("s_nop 3" ::"v"(x.v[0]), "v"(x.v[1]), "v"(x.v[2]), "v"(x.v[3]) : "memory");
+  else if constexpr (VPL == 2) asm volatile("s_nop 3" ::"v"(x.v[0]), "v"(x.v[1]) : "memory");
+  else asm volatile("s_nop 3" ::"v"(x.v[0]) : "memory");
 }
 template <int VPL>
 __device__ __forceinline__ void buf_store_row(BufRsrc r, int voff, int soff, const Row<VPL> &x) {

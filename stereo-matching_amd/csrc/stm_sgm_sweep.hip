@@ -331,7 +331,7 @@ __device__ __forceinline__ void sweep_image(const float *__restrict__ cost_all, 
                 q.x = __builtin_bit_cast(unsigned, x.v[j]); q.y = tag;
                 q.z = __builtin_bit_cast(unsigned, x.v[j + 1]); q.w = tag;
                 __builtin_amdgcn_raw_buffer_store_b128(q, pub_rs, (unsigned)dh * 8u, soff + (unsigned)j * 8u, kAuxSc1);
-                asm volatile("s_nop 1" ::"v"(q) : "memory");  // (hold_store_data: the store is still reading q)
+                asm volatile("s_nop 3" ::"v"(q) : "memory");  // (hold_store_data: the store is still reading q)
               }
             }
           }
