@@ -310,6 +310,33 @@ def latency_b1(device, reps=20):
         agg = float(np.median([e[1].elapsed_time(e[2]) for e in ev]))
         out[key] = {"ms_per_call": round(ssd + agg, 4), "ssd_ms": round(ssd, 4),
                     "sgm_wta_ms": round(agg, 4), "pairs_per_s": round(1e3 / (ssd + agg), 1)}
+        # The same call captured once into a HIP graph and replayed (what a caller with a fixed
+        # image size can do: one graph launch instead of the call's five to seven kernel and
+        # memset launches).  Extra information; a failure here never fails the run.
+        try:
+            plain = stereomatch.Pipeline(stereomatch.cost.SSD(D, kernel_size=7),
+                                         stereomatch.disparity_reduce.WinnerTakesAll(),
+                                         stereomatch.aggregation.Semiglobal(0.1, 0.2))
+            want = plain.estimate(Lg, Rg).clone()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                got = plain.estimate(Lg, Rg)
+            for _ in range(2):
+                graph.replay()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            a.record()
+            for _ in range(reps):
+                graph.replay()
+            b.record()
+            torch.cuda.synchronize()
+            ok = bool(torch.equal(got, want)) and plain.status() == 0
+            out[key]["graph_replay_ms_per_call"] = round(a.elapsed_time(b) / reps, 4) if ok else None
+            del graph, plain, got, want
+        except Exception as e:  # noqa: BLE001
+            print("latency_b1: graph replay of %s not measured (%r)" % (key, e), file=sys.stderr, flush=True)
+            out[key]["graph_replay_ms_per_call"] = None
         del pipe, cost
         torch.cuda.empty_cache()
     return out
