@@ -78,7 +78,11 @@ def test_register_soffset_buffer_stores_hold_their_data(tmp_path):
     pads the store-data hazard only for immediate soffsets, and on gfx950 the next VALU write
     to the data registers otherwise races with the store's read of them."""
     hipcc = "/opt/rocm/bin/hipcc"
-    for name in ("stm_sgm_sweep.hip", "stm_sgm_hwalk.hip", "stm_dp.hip"):
+    checked = ("stm_sgm_sweep.hip", "stm_sgm_hwalk.hip", "stm_dp.hip")
+    for f in os.listdir(CSRC):  # every unit that stores through a descriptor is in the list
+        if f.endswith(".hip") and re.search(r"raw_buffer_store|buf_store_row", open(os.path.join(CSRC, f)).read()):
+            assert f in checked, f + " stores through a buffer descriptor: add it to this test"
+    for name in checked:
         asm = str(tmp_path / (name + ".s"))
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                                "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
