@@ -314,6 +314,8 @@ def latency_b1(device, reps=20):
         # image size can do: one graph launch instead of the call's five to seven kernel and
         # memset launches).  Extra information; a failure here never fails the run.
         try:
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                raise RuntimeError("a process group is active: no stream capture beside its watchdog")
             plain = stereomatch.Pipeline(stereomatch.cost.SSD(D, kernel_size=7),
                                          stereomatch.disparity_reduce.WinnerTakesAll(),
                                          stereomatch.aggregation.Semiglobal(0.1, 0.2))
