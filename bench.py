@@ -101,6 +101,10 @@ class Job:
         self.right = torch.from_numpy(np.stack([p[1] for p in pairs])).to(device)
         self.cost_op = _TimedCost(stereomatch.cost.SSD(D, kernel_size=7))
         self.sgm = stereomatch.aggregation.Semiglobal(0.1, 0.2, form=form)
+        # In a multi-rank run a failed call is reported by check_status() on ALL ranks at a common
+        # point (all-reduced); the op's own deferred raise would fire on one rank alone, mid-loop,
+        # and leave the others in the next barrier.
+        self.sgm.raise_deferred = False
         self.pipe = stereomatch.Pipeline(self.cost_op, stereomatch.disparity_reduce.WinnerTakesAll(),
                                          self.sgm)
         self.disp = None

@@ -38,6 +38,8 @@
 // latency-bound by its dependent chain.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "stm_common.h"
 
 namespace stm {
@@ -420,6 +422,7 @@ __global__ __launch_bounds__(64) void dp_tile_kernel(const float *__restrict__ v
           v4u_t w4;
           w4.x = out_w[u]; w4.y = out_w[(u + 1) % LP]; w4.z = out_w[(u + 2) % LP]; w4.w = out_w[(u + 3) % LP];
           __builtin_amdgcn_raw_buffer_store_b128(w4, prs, dst, 4 * u, 0);
+          asm volatile("s_nop 3" ::"v"(w4) : "memory");  // (hold_store_data, stm_common.h: the store still reads w4)
         } else if constexpr (LP == 2) {
           v2u_t w2;
           w2.x = out_w[0]; w2.y = out_w[1 % LP];
@@ -681,13 +684,13 @@ __global__ __launch_bounds__(64) void dp_backtrack_ahead_kernel(const int8_t *__
 // batch size (1030 x 1040 x 1024: 6.2 -> 1.9 ms, four pairs 15.3 -> 6.0 ms).
 bool dp_prefers_wide(int H, int D, int batch) {
   if (D > 256) return true;
-  static int cus_of[16];
+  static std::atomic<int> cus_of[16];  // (any thread may call; a race stores the same value twice)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return false;
-  int cus = dev >= 0 && dev < 16 ? cus_of[dev] : 0;
+  int cus = dev >= 0 && dev < 16 ? cus_of[dev].load(std::memory_order_relaxed) : 0;
   if (cus == 0) {
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-    if (dev >= 0 && dev < 16) cus_of[dev] = cus;
+    if (dev >= 0 && dev < 16) cus_of[dev].store(cus, std::memory_order_relaxed);
   }
   const long long narrow_waves = (long long)batch * ((H + 3) / 4);
   return narrow_waves * 2 <= (long long)cus * 3;

@@ -183,7 +183,7 @@ int sgm_run_tiled(const float *cost, const float *left, float *out, int32_t *dis
   c.dlim = (flags & STM_SGM_FULL_MIN) ? D : D - 1;
   c.true_paths = (flags & STM_SGM_TRUE_PATHS) ? 1 : 0;
   c.accumulate = (flags & STM_SGM_ACCUMULATE) ? 1 : 0;
-  c.cooperative = (flags & STM_SGM_COOPERATIVE) != 0 || getenv("STM_SWEEP_COOPERATIVE") != nullptr;
+  c.cooperative = (flags & STM_SGM_COOPERATIVE) != 0;
   c.by_rows = form == kSgmTiledSweeps;
   // Segments per tile row (D = 64, 256 behind sweeps; stm_sgm_tiled_index.h, row_segs): finer units
   // balance better -- eight 1080p pairs are 1,080 tile rows for 256 workgroups -- and every
@@ -191,9 +191,11 @@ int sgm_run_tiled(const float *cost, const float *left, float *out, int32_t *dis
   // Measured, eight 1080p pairs: 32.4 / 30.7 / 29.6 / 29.6 ms with 1 / 2 / 3 / 4 segments, 32.7 with
   // the left-to-right direction walked instead of carried.
   c.segs = plan.G.nTC / 16 < 1 ? 1 : (plan.G.nTC / 16 > kMaxSegs ? kMaxSegs : plan.G.nTC / 16);
-  if (getenv("STM_TILE_SEGS")) c.segs = atoi(getenv("STM_TILE_SEGS"));  // (development)
-  c.segs = c.segs < 1 ? 1 : (c.segs > kMaxSegs ? kMaxSegs : c.segs);     // (the flag area holds kMaxSegs per tile row)
-  if (getenv("STM_TILE_NO_ROWS") && D != 128) c.by_rows = false;        // (development: A/B against the walked form)
+#ifdef STM_DEV_SWITCHES  // (development builds only, tools/build_probe.sh: the product reads no environment)
+  if (getenv("STM_TILE_SEGS")) c.segs = atoi(getenv("STM_TILE_SEGS"));
+  if (getenv("STM_TILE_NO_ROWS") && D != 128) c.by_rows = false;  // (A/B against the walked form)
+#endif
+  c.segs = c.segs < 1 ? 1 : (c.segs > kMaxSegs ? kMaxSegs : c.segs);  // (the flag area holds kMaxSegs per tile row)
   c.status_off = plan.status_off;
   c.group = plan.group;
   c.cus = plan.cus;

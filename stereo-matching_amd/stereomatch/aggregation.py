@@ -64,6 +64,12 @@ class Semiglobal:
         # Status word of the last tiled call, on its way to the host (see status()).
         self._status_host = None
         self._status_event = None
+        self._status_word = None   # the last call's word once status() has read (consumed) it
+        # False: the next call does not raise for a failed previous one by itself -- for callers
+        # inside a collective context, which read status() on every rank at a common point and
+        # agree on the verdict (distributed.estimate_sharded, bench.py): a raise on one rank
+        # alone would leave the others waiting in the next collective.
+        self.raise_deferred = True
 
     def __call__(self, cost_volume: torch.Tensor, left_image: torch.Tensor,
                  sga_volume: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -150,6 +156,7 @@ class Semiglobal:
     # synchronisation points (Pipeline.status(), distributed.estimate_sharded, bench.py).
     def _post_status(self, device) -> None:
         self._status_event = None
+        self._status_word = None
         if (self._last_form != _native.STM_SGM_FORM_SWEEPS or self._workspace is None
                 or self._workspace.numel() < 4):
             return  # only the row sweeps have waits that can expire
@@ -163,7 +170,7 @@ class Semiglobal:
 
     def _raise_if_failed(self, block: bool) -> None:
         ev = self._status_event
-        if ev is None or not (block or ev.query()):
+        if ev is None or not (block or ev.query()) or not (block or self.raise_deferred):
             return
         ev.synchronize()
         self._status_event = None
@@ -177,19 +184,26 @@ class Semiglobal:
     def status(self) -> int:
         """Status word of the last call (waits for that call): 0 = ok; bit 0 = a bounded wait
         inside the tiled form's row sweeps expired and that call's results are invalid.  The
-        paired form and the walk-fed tiles have no waits and always report 0."""
+        paired form and the walk-fed tiles have no waits and always report 0.
+
+        Reading the word CONSUMES the pending report: the caller has been told, so the next
+        call on this op does not raise for it again (the documented recovery -- re-running the
+        call with ``form="paired"`` -- is such a next call)."""
         if (self._last_form != _native.STM_SGM_FORM_SWEEPS or self._workspace is None
                 or self._workspace.numel() < 4):
             return 0
         if self._status_event is not None:
             self._status_event.synchronize()
-            return int(self._status_host.item())
-        torch.cuda.synchronize(self._workspace.device)
-        return int(self._workspace[:4].view(torch.int32).item())
+            self._status_event = None
+            self._status_word = int(self._status_host.item())
+        if self._status_word is None:  # (a captured call: nothing was posted)
+            torch.cuda.synchronize(self._workspace.device)
+            self._status_word = int(self._workspace[:4].view(torch.int32).item())
+        return self._status_word
 
     def check(self) -> None:
         """Waits for the last call and raises RuntimeError if its status word is set."""
-        if self.status():
-            self._raise_if_failed(block=True)
+        word = self.status()
+        if word:
             raise RuntimeError("Semiglobal: the last tiled aggregation's results are invalid "
-                               "(status word set); re-run with Semiglobal(form='paired')")
+                               "(status word %d); re-run with Semiglobal(form='paired')" % word)

@@ -78,11 +78,13 @@ def estimate_sharded(pipeline, lefts: torch.Tensor, rights: torch.Tensor, group=
         # The gather hands this rank's maps to everybody: the one place where an invalid result
         # (status word of the tiled aggregation: its row sweeps did not have the device's CUs to
         # themselves) must not pass.  Recovery as the C ABI documents it: the paired form.
+        # (status() consumes the report, so the re-run below is not refused for it.)
         status = getattr(pipeline, "status", None)
-        if callable(status) and status():
+        word = int(status()) if callable(status) else 0
+        if word:
             import warnings
             warnings.warn("stereomatch: tiled aggregation reported status %d on rank %d; "
-                          "recomputing this shard with the paired form" % (status(), rank))
+                          "recomputing this shard with the paired form" % (word, rank))
             agg = pipeline.aggregation
             form, agg.form = agg.form, "paired"
             try:

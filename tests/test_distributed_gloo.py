@@ -63,3 +63,61 @@ def test_two_ranks_shard_and_gather(tmp_path, oracle, n_pairs):
     for r in range(world):
         got = np.load(tmp_path / ("rank%d.npy" % r))
         assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def _worker_recovery(rank, world, port, n_pairs, H, W, D, out_dir):
+    """Rank 1's first estimate 'fails' (its status word is set): it must re-run with the paired
+    form and still arrive at the gather -- a raise on one rank would hang the other."""
+    for p in (ROOT, os.path.join(ROOT, "stereo-matching_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import warnings
+    import torch.distributed as dist
+    import oracle
+    from stereomatch.distributed import estimate_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class Agg:
+        form = "auto"
+
+    class Pipe:  # the product Pipeline's surface estimate_sharded relies on
+        def __init__(self):
+            self.aggregation = Agg()
+            self.forms = []
+            self._word = 0
+
+        def estimate(self, left, right):
+            self.forms.append(self.aggregation.form)
+            self._word = 1 if (rank == 1 and self.aggregation.form != "paired") else 0
+            bad = 7 if self._word else 0  # an invalid map, if it were ever gathered
+            return torch.from_numpy(np.stack([oracle.wta(oracle.ssd(l.numpy(), r.numpy(), D, 3)) + bad
+                                              for l, r in zip(left, right)]))
+
+        def status(self):
+            word, self._word = self._word, 0  # consumed by the read, as Semiglobal.status()
+            return word
+
+    pairs = [oracle.synthetic_pair(H, W, seed=s) for s in range(n_pairs)]
+    lefts = torch.from_numpy(np.stack([p[0] for p in pairs]))
+    rights = torch.from_numpy(np.stack([p[1] for p in pairs]))
+    pipe = Pipe()
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        gathered = estimate_sharded(pipe, lefts, rights)
+    assert pipe.forms == (["auto", "paired"] if rank == 1 else ["auto"]) and pipe.aggregation.form == "auto"
+    assert (len(caught) == 1) == (rank == 1)
+    np.save(os.path.join(out_dir, "rec%d.npy" % rank), gathered.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_failed_shard_is_recomputed_before_the_gather(tmp_path, oracle):
+    H, W, D, world, n_pairs = 12, 20, 8, 2, 4
+    mp.spawn(_worker_recovery, args=(world, _free_port(), n_pairs, H, W, D, str(tmp_path)), nprocs=world,
+             join=True)
+    want = np.stack([oracle.wta(oracle.ssd(*oracle.synthetic_pair(H, W, seed=s), D, 3))
+                     for s in range(n_pairs)])
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / ("rec%d.npy" % r)), want)

@@ -262,6 +262,53 @@ def test_failed_call_is_reported_by_the_next_call(device):
     assert sgm.status() == 0
 
 
+def test_sharded_estimate_recovers_from_a_reported_failure(device):
+    """estimate_sharded's recovery.  A tiled call whose status word says "invalid" is
+    re-run with the paired form on the same op; reading the word consumes the report, so the
+    re-run is not refused, the maps are the paired form's, and nothing raises."""
+    import stereomatch
+    from stereomatch.distributed import estimate_sharded
+    H, W, D, B = 40, 90, 128, 2
+    rng = np.random.default_rng(5)
+    L = torch.from_numpy(rng.integers(0, 256, size=(B, H, W)).astype(np.float32)).to(device)
+    R = torch.roll(L, -3, dims=2)
+
+    def pipe(form):
+        return stereomatch.Pipeline(stereomatch.cost.SSD(D), stereomatch.disparity_reduce.WinnerTakesAll(),
+                                    stereomatch.aggregation.Semiglobal(form=form))
+    want = pipe("paired").estimate(L, R).clone()
+    p = pipe("tiled")
+    sgm = p.aggregation
+    post = sgm._post_status
+    calls = []
+
+    def failing_post(dev):  # the first call's word arrives as 1: what a timed-out sweep leaves
+        post(dev)
+        calls.append(sgm._last_form)
+        if len(calls) == 1:
+            sgm._status_event.synchronize()
+            sgm._status_host.fill_(1)
+    sgm._post_status = failing_post
+    with pytest.warns(UserWarning, match="paired form"):
+        got = estimate_sharded(p, L, R)
+    assert len(calls) == 2 and calls[1] == stereomatch._native.STM_SGM_FORM_PAIRED
+    assert torch.equal(got, want)
+    assert sgm.form == "tiled" and p.status() == 0
+    # without the collective context's status() the same failure raises at the next call
+    sgm._post_status = post
+    p.estimate(L, R)
+    torch.cuda.synchronize()
+    sgm._status_host.fill_(1)
+    assert sgm.status() == 1 and sgm.status() == 1  # consumed, remembered
+    p.estimate(L, R)  # not refused
+    assert p.status() == 0
+    sgm.raise_deferred = False
+    p.estimate(L, R)
+    torch.cuda.synchronize()
+    sgm._status_host.fill_(1)
+    p.estimate(L, R)  # no implicit raise when the caller has taken the verdict over
+
+
 def test_tiled_forms_fall_back_where_they_do_not_apply(device, oracle):
     """Where the tiled forms stop (include/stereomatch_hip.h): D other than 64 / 128 / 256 (e.g.
     the reference limit's D = 512, src/semiglobal_gpu.cu:109-120), SINGLE_PASSES and

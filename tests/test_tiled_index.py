@@ -91,8 +91,9 @@ def test_register_soffset_buffer_stores_hold_their_data(tmp_path):
         lines = open(asm).read().splitlines()
         n = 0
         for i, l in enumerate(lines):
-            m = re.match(r"\s*buffer_store_dword(x[234])?\s+(v\[?\d+[:\d\]]*), v\d+, s\[\d+:\d+\], (s\d+) offen", l)
-            if not m:
+            m = re.match(r"\s*buffer_store_dword(x[234])?\s+(v\[?\d+[:\d\]]*), (?:v\d+|off), s\[\d+:\d+\], (\S+)", l)
+            # (every store with a register soffset, and every 16-byte store whatever its soffset)
+            if not m or not (m.group(3).startswith("s") or m.group(1) == "x4"):
                 continue
             n += 1
             lo, hi = _vrange(m.group(2))
