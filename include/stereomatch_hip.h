@@ -183,6 +183,15 @@ int stm_birchfield_ex_f32(const float *left, const float *right, float *cost,
  *                   picks by itself for single pairs and small batches at D >= 128;
  *                   STM_SGM_TILED means the sweep-fed variant wherever the device can hold it. */
 #define STM_SGM_WALKS 512
+/*   STM_SGM_SKEW    use the SKEWED-TILE form wherever it covers the call (D = 128, no ACCUMULATE /
+ *                   SINGLE_PASSES / EXACT_NONFINITE): two passes over sheared 8x8 tiles, each
+ *                   reading the cost volume once and carrying its four directions from tile to
+ *                   tile (stm_sgm_skew.hip): ~18 instead of 30 bytes per element.  Bands of tiles
+ *                   wait for the band above / below through progress counters; units are taken by
+ *                   ticket, so there is NO residency requirement; the waits are bounded all the
+ *                   same and report through the status word like the sweeps'.  What the library
+ *                   picks by itself for large D = 128 batches. */
+#define STM_SGM_SKEW 1024
 size_t stm_sgm_workspace_bytes(int H, int W, int D, int batch, int flags);
 /* 1 when stm_sgm_f32 / stm_sgm_wta_f32 select the tiled form for this shape on the current
  * device, i.e. the workspace starts with the status word (a 256-byte header; also when such
@@ -193,6 +202,7 @@ int stm_sgm_uses_tiles(int H, int W, int D, int batch, int flags);
 #define STM_SGM_FORM_PAIRED 0
 #define STM_SGM_FORM_SWEEPS 1
 #define STM_SGM_FORM_WALKS 2
+#define STM_SGM_FORM_SKEW 3
 int stm_sgm_form(int H, int W, int D, int batch, int flags);
 /* The status word's value given a HOST copy of the workspace's first 4 bytes (a helper for
  * bindings that cannot cast); 0 = ok. */

@@ -316,6 +316,32 @@ __device__ __forceinline__ void buf_store_row(BufRsrc r, int voff, int soff, con
   hold_store_data<VPL>(x);
 }
 
+// 16-byte rows through a descriptor with a cache policy (aux bits of the raw buffer builtins:
+// kAuxSc1 = sc1, i.e. served by / written through to the memory side: data that another
+// workgroup of the SAME launch wrote or will read -- MI355X guide, Guideline 16).  An offset at or
+// beyond the descriptor's size (kNowhere) is an access the hardware drops: loads return 0.
+constexpr int kBufSc1 = 16;
+constexpr unsigned kNowhere = 0xfffffff0u;
+template <int AUX>
+__device__ __forceinline__ Row<4> buf_load_row4(BufRsrc r, unsigned voff, unsigned soff) {
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  const v4u q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, AUX);
+  const unsigned q0 = q.x, q1 = q.y, q2 = q.z, q3 = q.w;  // (see buf_load_row)
+  Row<4> o;
+  o.v[0] = __builtin_bit_cast(float, q0); o.v[1] = __builtin_bit_cast(float, q1);
+  o.v[2] = __builtin_bit_cast(float, q2); o.v[3] = __builtin_bit_cast(float, q3);
+  return o;
+}
+template <int AUX>
+__device__ __forceinline__ void buf_store_row4(BufRsrc r, unsigned voff, unsigned soff, const Row<4> &x) {
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  v4u q;
+  q.x = __builtin_bit_cast(unsigned, x.v[0]); q.y = __builtin_bit_cast(unsigned, x.v[1]);
+  q.z = __builtin_bit_cast(unsigned, x.v[2]); q.w = __builtin_bit_cast(unsigned, x.v[3]);
+  __builtin_amdgcn_raw_buffer_store_b128(q, r, (int)voff, (int)soff, AUX);
+  hold_store_data<4>(x);
+}
+
 // Loads / stores of data that another workgroup of the SAME launch has written / will read:
 // relaxed atomics at agent scope, dword by dword (sc1 accesses: served by / written through to
 // the memory side.  MI355X guide, Guideline 16: the per-XCD L2s are not coherent with each

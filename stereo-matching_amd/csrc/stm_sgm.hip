@@ -754,7 +754,7 @@ extern "C" size_t stm_sgm_workspace_bytes(int H, int W, int D, int batch, int fl
     // Chosen by the library, not forced: a call whose pointers turn out not to be 16-byte
     // aligned takes the paired form behind the same header, so the workspace fits either.
     const size_t tiled = stm::sgm_tiled_workspace_bytes(H, W, D, batch, flags);
-    if (flags & (STM_SGM_TILED | STM_SGM_WALKS)) return tiled;
+    if (flags & (STM_SGM_TILED | STM_SGM_WALKS | STM_SGM_SKEW)) return tiled;
     const size_t paired = stm::kSgmWorkspaceHeader +
         sgm_plan(H, W, D, batch, true, (flags & STM_SGM_TRUE_PATHS) != 0).total_floats * sizeof(float);
     return tiled > paired ? tiled : paired;
@@ -769,7 +769,7 @@ extern "C" int stm_sgm_uses_tiles(int H, int W, int D, int batch, int flags) {
 extern "C" int stm_sgm_form(int H, int W, int D, int batch, int flags) {
   if (H <= 0 || W <= 0 || D <= 0 || batch <= 0 || D > STM_MAX_DISPARITY) return STM_SGM_FORM_PAIRED;
   static_assert(stm::kSgmPaired == STM_SGM_FORM_PAIRED && stm::kSgmTiledSweeps == STM_SGM_FORM_SWEEPS &&
-                    stm::kSgmTiledWalks == STM_SGM_FORM_WALKS, "form codes");
+                    stm::kSgmTiledWalks == STM_SGM_FORM_WALKS && stm::kSgmSkew == STM_SGM_FORM_SKEW, "form codes");
   return (int)stm::sgm_form(H, W, D, batch, flags);
 }
 
@@ -847,7 +847,7 @@ static int sgm_run(const float *cost, const float *left, float *out, int32_t *di
               "stm_sgm_wta_f32: needs a disparity pointer and the paired form");
 #if !STM_SGM_EXACT
   if (sgm_tiled_selected(H, W, D, batch, flags)) {
-    if ((flags & (STM_SGM_TILED | STM_SGM_WALKS)) || sgm_tiled_aligned(cost, out, workspace, final_mode))
+    if ((flags & (STM_SGM_TILED | STM_SGM_WALKS | STM_SGM_SKEW)) || sgm_tiled_aligned(cost, out, workspace, final_mode))
       return sgm_run_tiled(cost, left, out, disp, H, W, D, penalty1, penalty2, flags, workspace,
                            workspace_bytes, batch, as_stream(stream), final_mode);
     // The library's own choice, but this call's pointers are not 16-byte aligned (e.g. an offset

@@ -1,0 +1,215 @@
+// Index model of the SKEWED-TILE form of the semiglobal aggregation (stm_sgm_skew.hip): the
+// geometry of its tiles and workspace and every expression by which its kernels form a global
+// address.  Plain C++, host and device: the kernels call these functions, and
+// tests/host/skew_index_check.cpp (tests/test_tiled_index.py, no GPU) evaluates them for every
+// tile of a grid of shapes and asserts that each access lies inside its buffer.
+//
+// Why skewed tiles.  The tiled form (stm_sgm_tiled.hip) rebuilds all eight directions of an 8 x 8
+// tile from border states, and those border states cost three more reads of the cost volume (two
+// row sweeps and a walk) in which every direction is computed a second time.  A tile pass could
+// CARRY a direction from tile to tile instead -- but with rectangular tiles only three of the four
+// "forward" directions (right, down, down-right, down-left) are causal in one tile order: the
+// down-left direction enters a tile from its RIGHT neighbour, the other two from the left one.
+// Shearing every 8-row band by one column per row makes all four causal: with
+//     tile (i, j), pixel (u, r), u, r in [0, 8):   x = 8 j + u - r,   y = 8 i + r
+// the four directions step by (du, dr) = right (1, 0), down (1, 1), down-right (2, 1), down-left
+// (0, 1): every one of them leaves a tile to the right or downwards, and a tile depends only on
+// the tile to its left (same workgroup: registers) and on tiles j and j + 1 of the band above
+// (another workgroup: row border states in memory + a progress counter).  Two passes then do
+// everything, each reading the cost volume once:
+//   reverse pass  (bands bottom-up, tiles right-to-left): carries left, up, up-left, up-right and
+//                 stores their states where a path leaves a tile: top rows (rowb) and left sides
+//                 (side blocks);
+//   forward pass  (bands top-down, tiles left-to-right): carries right, down, down-right,
+//                 down-left, rebuilds the four inverse directions inside the tile from the
+//                 reverse pass's states, adds all eight in the reference's order into the
+//                 LDS-resident sum tile and reduces / stores it.
+// 8 + ~10 bytes per element instead of 30, and every direction computed 1.5 times instead of 2.
+//
+// All offsets are in floats (4-byte elements) unless a name says otherwise.
+#pragma once
+
+#include "stm_sgm_tiled_index.h"  // STM_HD, imin_/imax_, Counts/seg_counts
+
+namespace stm {
+namespace skew {
+
+using tiled::imax_;
+using tiled::imin_;
+
+using tiled::kT;                 // tile side (8)
+constexpr int kSide = 29;          // states a tile hands to its left / right neighbour (side block)
+constexpr int kHeaderFloats = 64;  // 256 bytes: status word, two unit tickets, padding
+constexpr int kTicketRev = 1, kTicketFwd = 2;  // 32-bit words of the header
+
+// Pairs in the reference's order: 0 right / left, 1 down / up, 2 down-right / up-left,
+// 3 down-left / up-right.  Step of a pair's FORWARD direction in the image and in a tile.
+STM_HD constexpr int img_dx(int phase) { return phase == 0 ? 1 : (phase == 1 ? 0 : (phase == 2 ? 1 : -1)); }
+STM_HD constexpr int img_dy(int phase) { return phase == 0 ? 0 : 1; }
+STM_HD constexpr int tile_du(int phase) { return phase == 0 ? 1 : (phase == 1 ? 1 : (phase == 2 ? 2 : 0)); }
+STM_HD constexpr int tile_dr(int phase) { return phase == 0 ? 0 : 1; }
+// Distance of two consecutive pixels of a line in a tile's pixel index r * 8 + u.
+STM_HD constexpr int tile_pstep(int phase) { return tile_dr(phase) * kT + tile_du(phase); }
+
+struct SkewGeom {
+  int H, W, D;
+  int nTR, nTC;         // bands of 8 rows; skewed tile columns: u = x + r covers [0, W + 7)
+  int batch;
+  long long prog_off;   // [2 passes][batch][nTR] 32-bit progress counters (tiles finished in a band)
+  long long img_off;    // per image: [6][nTR][W][D] row border states, then [nTR][nTC][kSide][D] side blocks
+  long long img_floats;
+  long long side_in_img;  // offset of the side blocks inside an image's block
+};
+
+// Lays the workspace out; returns false when an image's blocks do not fit the 32-bit byte offsets
+// of a buffer descriptor.  `zero_floats`: the head (status, tickets, progress counters) that
+// every call clears.
+STM_HD bool make_geom(int H, int W, int D, int batch, SkewGeom &G, long long &total_floats,
+                      long long &zero_floats) {
+  G.H = H; G.W = W; G.D = D;
+  G.nTR = (H + kT - 1) / kT;
+  G.nTC = (W + kT - 1 + kT - 1) / kT;
+  G.batch = batch;
+  long long off = kHeaderFloats;
+  G.prog_off = off;
+  off += (2ll * batch * G.nTR + 3) / 4 * 4;  // (keeps what follows 16-byte aligned)
+  zero_floats = off;
+  G.img_off = off;
+  G.side_in_img = 6ll * G.nTR * W * D;
+  G.img_floats = G.side_in_img + (long long)G.nTR * G.nTC * kSide * D;
+  off += G.img_floats * batch;
+  total_floats = off;
+  const long long lim = 0xfffffff0ll;  // (offsets >= this mark "no access" in the kernels)
+  return (long long)H * W * D * 4 < lim && G.img_floats * 4 < lim;
+}
+
+// ---- pixels -----------------------------------------------------------------------------------
+STM_HD int tile_x(int j, int u, int r) { return kT * j + u - r; }
+STM_HD int tile_y(int i, int r) { return kT * i + r; }
+STM_HD bool in_image(const SkewGeom &G, int x, int y) { return x >= 0 && x < G.W && y >= 0 && y < G.H; }
+
+// A tile all of whose pixels and all of whose pixels' eight neighbours lie inside the image: no
+// path begins in it, every access of its fast form is in range.
+STM_HD bool tile_fast(const SkewGeom &G, int i, int j) {
+  return i >= 1 && kT * i + kT < G.H && j >= 1 && kT * j + kT < G.W;
+}
+
+// ---- row border states --------------------------------------------------------------------------
+// Direction index: 0 down, 1 down-right, 2 down-left -- state AFTER the pixel (x, 8 t + 7), the last
+// row of band t; 3 up, 4 up-left, 5 up-right -- state after the pixel (x, 8 t), the band's first row.
+// Offset inside an image's block.
+STM_HD long long rowb_in_img(const SkewGeom &G, int dir, int t, int x) {
+  return (((long long)dir * G.nTR + t) * G.W + x) * (long long)G.D;
+}
+// ---- side blocks --------------------------------------------------------------------------------
+// Block (t, j): the states with which the leftward directions LEAVE tile j of band t to the left,
+// i.e. after its pixels (0, r) (left: r = 0..7 -> index r; up: r = 1..7 -> 7 + r) and (u, r), u in
+// {0, 1}, r = 1..7 (up-left: 15 + 2 (r - 1) + u).  Tile j - 1 of the forward pass enters its
+// inverse chains from them.
+STM_HD int side_idx_left(int r) { return r; }
+STM_HD int side_idx_up(int r) { return 7 + r; }
+STM_HD int side_idx_upleft(int u, int r) { return 15 + 2 * (r - 1) + u; }
+STM_HD long long side_in_img(const SkewGeom &G, int t, int j, int idx) {
+  return G.side_in_img + (((long long)t * G.nTC + j) * kSide + idx) * (long long)G.D;
+}
+STM_HD long long img_base(const SkewGeom &G, int b) { return G.img_off + (long long)b * G.img_floats; }
+STM_HD long long prog_index(const SkewGeom &G, int pass, int b, int t) {
+  return ((long long)pass * G.batch + b) * G.nTR + t;
+}
+
+// ---- chains ---------------------------------------------------------------------------------------
+// The 64 pixels of a tile are, per pair, the 8 slots of 8 CHAINS.  A chain is made of up to three
+// PIECES, each a run of consecutive pixels of one line of the pair's direction inside the tile;
+// piece p + 1 lies on the line that piece p's line becomes in the NEXT tile to the right, so the
+// state with which the forward direction leaves piece p to the right is the state with which it
+// enters piece p + 1 of the same chain one tile later: a chain's owner carries it in registers.
+//   pair 0 (rows)            chain k: row r = k, one piece of 8.
+//   pair 3 (columns u = k)   one piece of 8, enters at the top, leaves at the bottom.
+//   pair 1 (lines u - r = c) chain c = 1..7: A = line c (8 - c pixels from (c, 0), top -> right side),
+//                            B = line c - 8 (c pixels from (0, 8 - c), left side -> bottom); chain 0: the
+//                            main diagonal (top -> bottom).
+//   pair 2 (lines u - 2r = c) chain c0 = 0..7: P0 = line c0 from (c0, 0) (top -> right), P1 = line
+//                            c0 - 8 (left -> right, or -> bottom for c0 < 2), P2 = line c0 - 16 (left ->
+//                            bottom; c0 >= 2): 1+4+3, 1+4+3, 2+4+2, 2+4+2, 3+4+1, 3+4+1, 4+4, 4+4 pixels.
+struct Piece {
+  int u, r, n;  // first pixel (forward order) and length
+};
+struct Chain {
+  Piece p[3];
+  int np;
+};
+STM_HD Chain chain_of(int phase, int k) {
+  Chain c;
+  c.np = 1;
+  c.p[1].u = c.p[1].r = c.p[1].n = 0;
+  c.p[2] = c.p[1];
+  if (phase == 0) {
+    c.p[0].u = 0; c.p[0].r = k; c.p[0].n = kT;
+  } else if (phase == 3) {
+    c.p[0].u = k; c.p[0].r = 0; c.p[0].n = kT;
+  } else if (phase == 1) {
+    c.p[0].u = k; c.p[0].r = 0; c.p[0].n = kT - k;
+    if (k > 0) {
+      c.np = 2;
+      c.p[1].u = 0; c.p[1].r = kT - k; c.p[1].n = k;
+    }
+  } else {
+    const int n0 = (kT - 1 - k) / 2 + 1;
+    c.p[0].u = k; c.p[0].r = 0; c.p[0].n = n0;
+    c.np = k >= 2 ? 3 : 2;
+    c.p[1].u = k & 1; c.p[1].r = (kT - k + (k & 1)) / 2; c.p[1].n = 4;
+    if (k >= 2) {
+      c.p[2].u = k & 1; c.p[2].r = (2 * kT - k + (k & 1)) / 2; c.p[2].n = kT - n0 - 4;
+    }
+  }
+  return c;
+}
+
+// How the inverse passes of the line through image pixel (gx, gy) count.
+STM_HD tiled::Counts line_counts(int phase, int gx, int gy, int H, int W, int true_paths) {
+  tiled::TiledGeom T;
+  T.H = H; T.W = W;
+  tiled::Seg s;
+  s.ex = gx; s.ey = gy; s.n = 1;
+  return tiled::seg_counts(phase, s, 0, 0, T, true_paths);
+}
+// ... for a whole tile (as tiled::h2_count_class): 1 = every inverse pass once, 0 = none at all,
+// 2 = some once and some not, 3 = the tile holds a line that counts several times or before its
+// forward pass.
+STM_HD int count_class(int phase, const SkewGeom &G, int i, int j, int true_paths) {
+  if (phase < 2 || true_paths) return 1;
+  const int e = G.W - G.H;
+  if (phase == 2) {
+    const int lo = kT * (j - i) - 2 * (kT - 1), hi = kT * (j - i) + (kT - 1);  // x - y over the tile
+    if (e > 0) {
+      if (lo <= e && e <= hi) return 3;
+      if (lo >= 0 && hi <= e - 1) return 0;
+      return (hi < 0 || lo > e) ? 1 : 2;
+    }
+    if (e < -1) {
+      if (lo <= e && e <= hi) return 3;
+      if (lo >= e + 1 && hi <= -1) return 0;
+      return (hi < e || lo >= 0) ? 1 : 2;
+    }
+    return 1;
+  }
+  if (e > 0) {
+    const int lo = kT * (i + j), hi = kT * (i + j) + (kT - 1);  // x + y over the tile
+    if (lo <= G.H - 1 && G.H - 1 <= hi) return 3;
+    if (lo >= G.H && hi <= G.W - 1) return 0;
+    return (hi < G.H - 1 || lo > G.W - 1) ? 1 : 2;
+  }
+  return 1;
+}
+
+// ---- what a tile reads and writes outside itself ---------------------------------------------
+// Tiles of the band above (forward pass) / below (reverse pass) whose row border states a tile
+// needs: j and j + 1 / j - 1 and j.  Progress a band's owner waits for before tile j (counted in
+// finished tiles from the band's first one in processing order): enough for tile j's own entries
+// and for prefetching those of the next tile.
+STM_HD int progress_needed(const SkewGeom &G, int jj /* tile's number in processing order */) {
+  return imin_(jj + 3, G.nTC);
+}
+
+}  // namespace skew
+}  // namespace stm

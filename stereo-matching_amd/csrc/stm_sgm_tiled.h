@@ -11,7 +11,7 @@ namespace stm {
 // workspace's status word can be set) or from per-path walks (single pairs and small batches;
 // no waits, the status word stays 0).  Deterministic in its arguments and the current device, so
 // that stm_sgm_workspace_bytes() and stm_sgm_f32() always agree.
-enum SgmForm { kSgmPaired = 0, kSgmTiledSweeps = 1, kSgmTiledWalks = 2 };
+enum SgmForm { kSgmPaired = 0, kSgmTiledSweeps = 1, kSgmTiledWalks = 2, kSgmSkew = 3 };
 SgmForm sgm_form(int H, int W, int D, int batch, int flags);
 inline bool sgm_tiled_selected(int H, int W, int D, int batch, int flags) {
   return sgm_form(H, W, D, batch, flags) != kSgmPaired;

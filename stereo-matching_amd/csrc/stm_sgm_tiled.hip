@@ -53,6 +53,7 @@
 
 #include <stdlib.h>
 
+#include "stm_sgm_skew_launch.h"
 #include "stm_sgm_tiled_launch.h"
 
 namespace stm {
@@ -108,6 +109,7 @@ bool shape_ok(int H, int W, int D, int batch, int flags) {
 }  // namespace
 
 SgmForm sgm_form(int H, int W, int D, int batch, int flags) {
+  if ((flags & STM_SGM_SKEW) && !(flags & STM_SGM_PAIRED) && skew_covers(H, W, D, batch, flags)) return kSgmSkew;
   if (!shape_ok(H, W, D, batch, flags)) return kSgmPaired;
   TiledGeom G;
   long long total = 0, zero = 0;
@@ -147,6 +149,7 @@ bool sgm_tiled_aligned(const void *cost, const void *out, const void *workspace,
 
 size_t sgm_tiled_workspace_bytes(int H, int W, int D, int batch, int flags) {
   if (sgm_form(H, W, D, batch, flags) == kSgmPaired) return 0;
+  if (sgm_form(H, W, D, batch, flags) == kSgmSkew) return skew_workspace_bytes(H, W, D, batch);
   TiledGeom G;
   long long total = 0, zero = 0;
   make_geom(H, W, D, batch, G, total, zero);
@@ -158,6 +161,14 @@ int sgm_run_tiled(const float *cost, const float *left, float *out, int32_t *dis
                   size_t workspace_bytes, int batch, hipStream_t stream, int final_mode) {
   const SgmForm form = sgm_form(H, W, D, batch, flags);
   STM_REQUIRE(form != kSgmPaired, STM_EUNSUPPORTED, "stm_sgm_f32: the tiled form does not cover this call");
+  if (form == kSgmSkew) {
+    STM_REQUIRE(sgm_tiled_aligned(cost, out, workspace, final_mode), STM_EINVAL,
+                "stm_sgm_f32: the tiled forms need 16-byte aligned volumes and workspace");
+    const int cus = device_cus();
+    STM_REQUIRE(cus > 0, STM_EHIP, "stm_sgm_f32: no HIP device");
+    return skew_run(cost, left, out, disp, H, W, D, penalty1, penalty2, flags, workspace, workspace_bytes, batch,
+                    stream, final_mode, cus);
+  }
   TiledPlan plan;
   if (form == kSgmTiledSweeps) {
     make_plan(H, W, D, batch, plan);

@@ -22,9 +22,9 @@ STM_SGM_KEEP_SUM = 4
 STM_SGM_FULL_MIN = 8
 STM_SGM_TRUE_PATHS = 16
 STM_SGM_EXACT_NONFINITE = 32
-STM_SGM_FORMS = {"auto": 0, "paired": 64, "tiled": 128, "walks": 512}
+STM_SGM_FORMS = {"auto": 0, "paired": 64, "tiled": 128, "walks": 512, "skew": 1024}
 STM_SGM_COOPERATIVE = 256
-STM_SGM_FORM_PAIRED, STM_SGM_FORM_SWEEPS, STM_SGM_FORM_WALKS = 0, 1, 2
+STM_SGM_FORM_PAIRED, STM_SGM_FORM_SWEEPS, STM_SGM_FORM_WALKS, STM_SGM_FORM_SKEW = 0, 1, 2, 3
 STM_DP_MODES = {"reference": 0, "corrected": 1}
 STM_BT_INDEXING = {"reference": 0, "padded": 1}
 

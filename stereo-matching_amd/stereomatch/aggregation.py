@@ -157,7 +157,7 @@ class Semiglobal:
     def _post_status(self, device) -> None:
         self._status_event = None
         self._status_word = None
-        if (self._last_form != _native.STM_SGM_FORM_SWEEPS or self._workspace is None
+        if (self._last_form not in (_native.STM_SGM_FORM_SWEEPS, _native.STM_SGM_FORM_SKEW) or self._workspace is None
                 or self._workspace.numel() < 4):
             return  # only the row sweeps have waits that can expire
         if torch.cuda.is_current_stream_capturing():
@@ -189,7 +189,7 @@ class Semiglobal:
         Reading the word CONSUMES the pending report: the caller has been told, so the next
         call on this op does not raise for it again (the documented recovery -- re-running the
         call with ``form="paired"`` -- is such a next call)."""
-        if (self._last_form != _native.STM_SGM_FORM_SWEEPS or self._workspace is None
+        if (self._last_form not in (_native.STM_SGM_FORM_SWEEPS, _native.STM_SGM_FORM_SKEW) or self._workspace is None
                 or self._workspace.numel() < 4):
             return 0
         if self._status_event is not None:
