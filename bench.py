@@ -202,10 +202,11 @@ def roofline(job, sgm_ms, traffic_and_note=(None, None)):
     tile = "sgm_tile_h2_kernel" if getattr(job, "D", 0) == 128 else "sgm_tile_kernel"
     kernels = {0: "paired form: sgm_ckpt_kernel + 4 x sgm_pair_kernel",
                1: "tiled form: sgm_hwalk_kernel + sgm_sweep_kernel (down, up) + " + tile,
-               2: "tiled form behind walks: sgm_bwalk_kernel + " + tile}[form]
+               2: "tiled form behind walks: sgm_bwalk_kernel + " + tile,
+               3: "skewed-tile form: sgm_skew_rev_kernel + sgm_skew_fwd_kernel"}[form]
     return {"bound": "hbm", "traffic_note": note,
             "kernel": "semiglobal aggregation with fused WTA (stm_sgm_wta_f32), " + kernels,
-            "form": {0: "paired", 1: "tiled (sweeps)", 2: "tiled (walks)"}[form],
+            "form": {0: "paired", 1: "tiled (sweeps)", 2: "tiled (walks)", 3: "skewed tiles"}[form],
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes": algorithmic, "ms": round(sgm_ms, 4),
@@ -410,7 +411,7 @@ def main():
                     help="rehearsal only: 1-rank RCCL group, gather code path exercised")
     ap.add_argument("--shared-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (with --backend gloo) on a 1-GPU box")
-    ap.add_argument("--form", default=None, choices=["auto", "paired", "tiled"],
+    ap.add_argument("--form", default=None, choices=["auto", "paired", "tiled", "walks", "skew"],
                     help="form of the aggregation (default: auto; paired with --shared-device, "
                          "since ranks sharing one GPU must not run tiled aggregations side by side)")
     args = ap.parse_args()

@@ -37,6 +37,23 @@ namespace {
 using namespace skew;
 using std::integral_constant;
 
+#ifndef STM_SKEW_FWD_PREFETCH_AT
+#define STM_SKEW_FWD_PREFETCH_AT 2  // the next tile's cost rows are requested behind pair 1 / pair 2
+#endif
+#ifndef STM_SKEW_REV_OCC
+#define STM_SKEW_REV_OCC 2  // workgroups of the reverse pass per CU (registers: 512 / (4 x this) per lane)
+#endif
+// Timing experiments (tools/build_skew_variants.sh; results are wrong with any of them):
+#ifdef STM_SKEW_X_PLAIN
+constexpr int kXSc1 = 0;
+#else
+constexpr int kXSc1 = kBufSc1;
+#endif
+#ifdef STM_SKEW_X_NOSTORE
+#define STM_X_STORE(...) do {} while (0)
+#else
+#define STM_X_STORE(...) __VA_ARGS__
+#endif
 constexpr int kD = 128;
 constexpr int kRowBytes = kD * 4;            // one pixel's disparities
 constexpr int kSumPixBytes = st_stride(kD) * 4;
@@ -352,8 +369,8 @@ __device__ __forceinline__ void fwd_pair(const PK &K, const Row<4> (&Ef)[3], con
   auto note_exit = [&](auto s_) {
     constexpr int s = decltype(s_)::value;
     if constexpr (s == NA - 1) Xf[0] = pf;
-    if constexpr (NA < kT && s == NB - 1) Xf[1] = pf;
-    if constexpr (NB < kT && s == kT - 1) Xf[2] = pf;
+    if constexpr (NA < kT ? s == NB - 1 : s == kT - 1) Xf[1] = pf;  // (a piece the chain does not have: a defined value)
+    if constexpr (s == kT - 1) Xf[2] = pf;
   };
   if (run_inv) {
     Row<4> cf = h2_lds_row(Ct, addr(integral_constant<int, 0>()));
@@ -498,12 +515,13 @@ __device__ __forceinline__ void rev_pairs(const PK &KA, const Row<4> (&Ea)[3], R
       pa = sel_row(fa.begin_i, ca, pa);
       pb = sel_row(fb.begin_i, cb, pb);
     }
+    // (pieces a chain does not have get a defined value too)
     if constexpr (r == 0) Xa[0] = pa;
-    if constexpr (NAA < kT && r == NAA) Xa[1] = pa;
-    if constexpr (NBA < kT && r == NBA) Xa[2] = pa;
+    if constexpr (NAA < kT ? r == NAA : r == 0) Xa[1] = pa;
+    if constexpr (NBA < kT ? r == NBA : r == 0) Xa[2] = pa;
     if constexpr (r == 0) Xb[0] = pb;
-    if constexpr (NAB < kT && r == NAB) Xb[1] = pb;
-    if constexpr (NBB < kT && r == NBB) Xb[2] = pb;
+    if constexpr (NAB < kT ? r == NAB : r == 0) Xb[1] = pb;
+    if constexpr (NBB < kT ? r == NBB : r == 0) Xb[2] = pb;
     ca = can;
     cb = cbn;
   };
@@ -516,13 +534,22 @@ __device__ __forceinline__ void rev_pairs(const PK &KA, const Row<4> (&Ea)[3], R
 // ---- progress counters --------------------------------------------------------------------------
 // Waits (one wave) until *p >= need.  Bounded like the sweeps' waits: ~2 s, then the status word is
 // set and nobody waits again.
-__device__ __forceinline__ void wait_progress(const unsigned *p, unsigned need, unsigned *status, bool &dead) {
-  if (dead) return;
-  if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return;
+// `seen`: the counter's value when this wave last looked (it only grows): no load at all while
+// that already suffices -- a band's owner that runs well behind its neighbour polls once per
+// several tiles.
+__device__ __forceinline__ void wait_progress(const unsigned *p, unsigned need, unsigned &seen, unsigned *status,
+                                              bool &dead) {
+#ifdef STM_SKEW_NOWAIT  // (timing experiment: results are wrong)
+  return;
+#endif
+  if (dead || seen >= need) return;
+  seen = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (seen >= need) return;
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   for (;;) {
     __builtin_amdgcn_s_sleep(8);
-    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return;
+    seen = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (seen >= need) return;
     if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { dead = true; return; }
     if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
       dead = true;
@@ -586,14 +613,14 @@ template <int FINAL, bool GEN>
 __device__ __forceinline__ void fwd_tile(const SkewArgs &P, const TileCtx &T, const TileCtx &Tn, bool have_next,
                                          const PK &K0, const PK &K1, const PK &K2, const PK &K3, FwdCarry &C,
                                          FwdPre &N, const float *image, float *Ct, float *St, const float *Ip,
-                                         StepCtxH2 &X, const LaneId &L, int lane) {
+                                         StepCtxH2 &X, const LaneId &L, int lane, unsigned *publish) {
   const SkewGeom &G = P.G;
   const int w = L.w;
   const int cls2 = GEN ? 3 : count_class(2, G, T.i, T.j, P.true_paths);
   const int cls3 = GEN ? 3 : count_class(3, G, T.i, T.j, P.true_paths);
   // Entries of pairs 2 and 3 (a global load takes longer than a pair: pairs 0 and 1 cover them).
-  const Row<4> e2t = buf_load_row4<kBufSc1>(T.wsb, rowb_off(G, T, 1, T.i - 1, K2.ft, false), 0);
-  const Row<4> e3t = buf_load_row4<kBufSc1>(T.wsb, rowb_off(G, T, 2, T.i - 1, K3.ft, false), 0);
+  const Row<4> e2t = buf_load_row4<kXSc1>(T.wsb, rowb_off(G, T, 1, T.i - 1, K2.ft, false), 0);
+  const Row<4> e3t = buf_load_row4<kXSc1>(T.wsb, rowb_off(G, T, 2, T.i - 1, K3.ft, false), 0);
   Row<4> Ei2[3], Ei3[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) Ei2[q] = buf_load_row4<0>(T.wsb, fwd_ie_off(G, T, 4, K2.ie[q]), 0);
@@ -613,33 +640,41 @@ __device__ __forceinline__ void fwd_tile(const SkewArgs &P, const TileCtx &T, co
   Ef[0] = sel_row(K1.carry_first, C.c1, N.e1t);
   Ef[1] = sel_row(K1.carry_first, N.e1t, C.c1);
   Ei[0] = N.e1i[0]; Ei[1] = N.e1i[1]; Ei[2] = N.e1i[1];
-  fwd_pair_w<1, FINAL, GEN>(w, K1, Ef, Ei, Xf, 1, G, T, P.true_paths, Ct, St, pen1, X, L, [] { lds_barrier(); });
+  fwd_pair_w<1, FINAL, GEN>(w, K1, Ef, Ei, Xf, 1, G, T, P.true_paths, Ct, St, pen1, X, L, [&] {
+#ifndef STM_SKEW_X_NODRAIN
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores of the previous tile have landed
+#endif
+    lds_barrier();
+    if (publish && threadIdx.x == 0) publish_progress(publish, (unsigned)T.j);
+  });
   {
     const bool main_diag = !K1.restart1;
     C.c1 = sel_row(K1.carry_first, Xf[1], Xf[0]);
     const Row<4> bottom = sel_row(K1.carry_first && !main_diag, Xf[0], Xf[1]);
-    buf_store_row4<kBufSc1>(T.wsb, rowb_off(G, T, 0, T.i, K1.fb, true), 0, bottom);
+    STM_X_STORE(buf_store_row4<kXSc1>(T.wsb, rowb_off(G, T, 0, T.i, K1.fb, true), 0, bottom));
   }
-  // The next tile's cost rows and its first entries (two pairs are still ahead to cover them).
-  prefetch_cost(N.cost, G, Tn, image, L);
-  N.e0i = buf_load_row4<0>(Tn.wsb, fwd_ie_off(G, Tn, 0, K0.ie[0]), 0);
-  N.e1t = buf_load_row4<kBufSc1>(Tn.wsb, have_next ? rowb_off(G, Tn, 0, Tn.i - 1, K1.ft, false) : kNowhere, 0);
-  N.e1i[0] = buf_load_row4<0>(Tn.wsb, fwd_ie_off(G, Tn, 3, K1.ie[0]), 0);
-  N.e1i[1] = buf_load_row4<0>(Tn.wsb, fwd_ie_off(G, Tn, 3, K1.ie[1]), 0);
+  // The next tile's cost rows and its first entries.
+  auto prefetch_next = [&] {
+    prefetch_cost(N.cost, G, Tn, image, L);
+    N.e0i = buf_load_row4<0>(Tn.wsb, fwd_ie_off(G, Tn, 0, K0.ie[0]), 0);
+    N.e1t = buf_load_row4<kXSc1>(Tn.wsb, have_next ? rowb_off(G, Tn, 0, Tn.i - 1, K1.ft, false) : kNowhere, 0);
+    N.e1i[0] = buf_load_row4<0>(Tn.wsb, fwd_ie_off(G, Tn, 3, K1.ie[0]), 0);
+    N.e1i[1] = buf_load_row4<0>(Tn.wsb, fwd_ie_off(G, Tn, 3, K1.ie[1]), 0);
+  };
+  if (STM_SKEW_FWD_PREFETCH_AT == 1) prefetch_next();
   // ---- pair 2: down-right / up-left
   Ef[0] = e2t; Ef[1] = C.c2a; Ef[2] = C.c2b;
   fwd_pair_w<2, FINAL, GEN>(w, K2, Ef, Ei2, Xf, cls2, G, T, P.true_paths, Ct, St, pen2, X, L, [] { lds_barrier(); });
   C.c2a = Xf[0];
-  if (w < 3) {
-    C.c2b = Xf[1];
-    buf_store_row4<kBufSc1>(T.wsb, rowb_off(G, T, 1, T.i, K2.fb, true), 0, Xf[2]);
-  } else {
-    buf_store_row4<kBufSc1>(T.wsb, rowb_off(G, T, 1, T.i, K2.fb, true), 0, Xf[1]);
-  }
+  C.c2b = Xf[1];  // (wave 3 has no third piece: unused there)
+  // (one unconditional store: a store under a condition is a branch, behind which the compiler
+  // can no longer count the accesses in flight -- DESIGN.md 4.1d)
+  STM_X_STORE(buf_store_row4<kXSc1>(T.wsb, rowb_off(G, T, 1, T.i, K2.fb, true), 0, sel_row(w < 3, Xf[2], Xf[1])));
+  if (STM_SKEW_FWD_PREFETCH_AT == 2) prefetch_next();
   // ---- pair 3: down-left / up-right
   Ef[0] = e3t; Ef[1] = e3t; Ef[2] = e3t;
   fwd_pair_w<3, FINAL, GEN>(w, K3, Ef, Ei3, Xf, cls3, G, T, P.true_paths, Ct, St, pen3, X, L, [] { lds_barrier(); });
-  buf_store_row4<kBufSc1>(T.wsb, rowb_off(G, T, 2, T.i, K3.fb, true), 0, Xf[0]);
+  STM_X_STORE(buf_store_row4<kXSc1>(T.wsb, rowb_off(G, T, 2, T.i, K3.fb, true), 0, Xf[0]));
 }
 
 __device__ __forceinline__ void make_tile(TileCtx &T, const SkewGeom &G, int i, int j) {
@@ -692,11 +727,12 @@ __global__ __launch_bounds__(4 * 64, 2) void sgm_skew_fwd_kernel(const float *__
     unsigned *prog_mine = prog + prog_index(G, 1, b, i);
     // Tile 0: everything that later tiles get from their predecessor's prefetch.
     make_tile(T, G, i, 0);
-    if (L.w == 0 && i > 0) wait_progress(prog_above, (unsigned)progress_needed(G, 0), status, dead);
+    unsigned seen = 0;
+    if (L.w == 0 && i > 0) wait_progress(prog_above, (unsigned)progress_needed(G, 0), seen, status, dead);
     __syncthreads();
     prefetch_cost(N.cost, G, T, image, L);
     N.e0i = buf_load_row4<0>(T.wsb, fwd_ie_off(G, T, 0, K0.ie[0]), 0);
-    N.e1t = buf_load_row4<kBufSc1>(T.wsb, rowb_off(G, T, 0, i - 1, K1.ft, false), 0);
+    N.e1t = buf_load_row4<kXSc1>(T.wsb, rowb_off(G, T, 0, i - 1, K1.ft, false), 0);
     N.e1i[0] = buf_load_row4<0>(T.wsb, fwd_ie_off(G, T, 3, K1.ie[0]), 0);
     N.e1i[1] = buf_load_row4<0>(T.wsb, fwd_ie_off(G, T, 3, K1.ie[1]), 0);
     C.c0 = N.e0i; C.c1 = N.e0i; C.c2a = N.e0i; C.c2b = N.e0i;  // (any defined value: tile 0's paths begin in it)
@@ -705,14 +741,15 @@ __global__ __launch_bounds__(4 * 64, 2) void sgm_skew_fwd_kernel(const float *__
       const bool have_next = j + 1 < G.nTC;
       make_tile(Tn, G, i, have_next ? j + 1 : j);
       stage_cost(N.cost, Ct, Ip, L);
-      // This wave's stores of the previous tile have landed; the band above is far enough ahead
-      // for this tile's entries and the next tile's prefetch; then the band's progress is published.
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (L.w == 0 && i > 0) wait_progress(prog_above, (unsigned)progress_needed(G, j), status, dead);
+      // The band above is far enough ahead for this tile's entries and the next tile's prefetch.
+      if (L.w == 0 && i > 0) wait_progress(prog_above, (unsigned)progress_needed(G, j), seen, status, dead);
       lds_barrier();
-      if (threadIdx.x == 0 && j > 0) publish_progress(prog_mine, (unsigned)j);
-      if (T.gen) fwd_tile<FINAL, true>(P, T, Tn, have_next, K0, K1, K2, K3, C, N, image, Ct, St, Ip, X, L, lane);
-      else fwd_tile<FINAL, false>(P, T, Tn, have_next, K0, K1, K2, K3, C, N, image, Ct, St, Ip, X, L, lane);
+      // (the band's own progress -- tiles < j are complete -- is published behind pair 1's barrier,
+      // in front of which every wave drains its stores: by then the previous tile's last stores
+      // have had a pair's time, a drain at the top of the tile would wait for them)
+      unsigned *publish = j > 0 ? prog_mine : nullptr;
+      if (T.gen) fwd_tile<FINAL, true>(P, T, Tn, have_next, K0, K1, K2, K3, C, N, image, Ct, St, Ip, X, L, lane, publish);
+      else fwd_tile<FINAL, false>(P, T, Tn, have_next, K0, K1, K2, K3, C, N, image, Ct, St, Ip, X, L, lane, publish);
       lds_barrier();
       if constexpr (FINAL != 0) skew_wta(St, L.w, lane, G, T.x0, T.y0, disp);
     }
@@ -729,16 +766,26 @@ struct RevCarry {
   Row<4> c0, c1, c2a, c2b;  // pair 0; pair 1 (B -> A); pair 2 (P1 -> P0, P2 -> P1)
 };
 
+// Bottom entries of a tile (the band below wrote them in this launch: sc1), requested a tile ahead.
+struct RevPre {
+  Pre cost;
+  Row<4> b1, b2, b3;
+};
+__device__ __forceinline__ void rev_bottoms(RevPre &N, const SkewGeom &G, const TileCtx &T, const PK &K1, const PK &K2,
+                                            const PK &K3) {
+  N.b1 = buf_load_row4<kXSc1>(T.wsb, rowb_off(G, T, 3, T.i + 1, K1.rb, false), 0);
+  N.b2 = buf_load_row4<kXSc1>(T.wsb, rowb_off(G, T, 4, T.i + 1, K2.rb, false), 0);
+  N.b3 = buf_load_row4<kXSc1>(T.wsb, rowb_off(G, T, 5, T.i + 1, K3.rb, false), 0);
+}
+
 template <bool GEN>
-__device__ __forceinline__ void rev_tile(const SkewArgs &P, const TileCtx &T, const PK &K0, const PK &K1,
-                                         const PK &K2, const PK &K3, RevCarry &C, const float *Ct, const float *Ip,
-                                         StepCtxH2 &X, const LaneId &L, int lane) {
+__device__ __forceinline__ void rev_tile(const SkewArgs &P, const TileCtx &T, const TileCtx &Tn, const PK &K0,
+                                         const PK &K1, const PK &K2, const PK &K3, RevCarry &C, RevPre &N,
+                                         const float *image, const float *Ct, const float *Ip, StepCtxH2 &X,
+                                         const LaneId &L, int lane, unsigned *publish, unsigned published) {
   const SkewGeom &G = P.G;
   const int w = L.w;
-  // Bottom entries (the band below wrote them in this launch: sc1).
-  const Row<4> b1 = buf_load_row4<kBufSc1>(T.wsb, rowb_off(G, T, 3, T.i + 1, K1.rb, false), 0);
-  const Row<4> b2 = buf_load_row4<kBufSc1>(T.wsb, rowb_off(G, T, 4, T.i + 1, K2.rb, false), 0);
-  const Row<4> b3 = buf_load_row4<kBufSc1>(T.wsb, rowb_off(G, T, 5, T.i + 1, K3.rb, false), 0);
+  const Row<4> b1 = N.b1, b2 = N.b2, b3 = N.b3;
   const float pen01 = chain_penalties<0, 1, 1, 1>(K0, kT, kT, K1, na_of(1, w), kT, Ip, P.p1, P.p2, lane);
   const float pen23 = chain_penalties<2, 1, 3, 1>(K2, na_of(2, w), nb_of(2, w), K3, kT, kT, Ip, P.p1, P.p2, lane);
   Row<4> Ea[3], Eb[3], Xa[3], Xb[3];
@@ -756,8 +803,16 @@ __device__ __forceinline__ void rev_tile(const SkewArgs &P, const TileCtx &T, co
     default: STM_REV01(4); break;
   }
 #undef STM_REV01
+  // This wave's stores of the PREVIOUS tile have landed (they have had half a tile's time; a drain
+  // at the top of the tile would wait for them), the workgroup's barrier, then the band's progress
+  // -- the tiles before this one are complete -- is published.
+#ifndef STM_SKEW_X_NODRAIN
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  lds_barrier();
+  if (publish && threadIdx.x == 0) publish_progress(publish, published);
   C.c0 = Xa[0];
-  buf_store_row4<0>(T.wsb, side_off(G, T, T.j, K0.rs[0]), 0, Xa[0]);
+  STM_X_STORE(buf_store_row4<0>(T.wsb, side_off(G, T, T.j, K0.rs[0]), 0, Xa[0]));
   {
     // slot order [q0, q1]; the inverse chain leaves q1 at slot NA (Xb[1]) and q0 at slot 0 (Xb[0]).
     // first half-wave: q1 = B leaves to the left (carry + side), q0 = A leaves at the top;
@@ -767,9 +822,12 @@ __device__ __forceinline__ void rev_tile(const SkewArgs &P, const TileCtx &T, co
     const Row<4> top = sel_row(K1.carry_first && !main_diag, Xb[1], Xb[0]);
     C.c1 = left;
     const unsigned so = K1.carry_first ? K1.rs[0] : K1.rs[1];
-    buf_store_row4<0>(T.wsb, side_off(G, T, T.j, so), 0, left);
-    buf_store_row4<kBufSc1>(T.wsb, rowb_off(G, T, 3, T.i, K1.rt, false), 0, top);
+    STM_X_STORE(buf_store_row4<0>(T.wsb, side_off(G, T, T.j, so), 0, left));
+    STM_X_STORE(buf_store_row4<kXSc1>(T.wsb, rowb_off(G, T, 3, T.i, K1.rt, false), 0, top));
   }
+  // The next tile's cost rows and bottom entries (half a tile ahead; held in registers no longer).
+  prefetch_cost(N.cost, G, Tn, image, L);
+  rev_bottoms(N, G, Tn, K1, K2, K3);
   // ---- pairs 2 (up-left) and 3 (up-right)
   Eb[0] = b3; Eb[1] = b3; Eb[2] = b3;
   if (w < 3) {
@@ -786,17 +844,15 @@ __device__ __forceinline__ void rev_tile(const SkewArgs &P, const TileCtx &T, co
   }
 #undef STM_REV23
   // pair 2: P0 leaves at the top; P1 to the left (-> the next tile's P0), P2 to the left (-> its P1)
-  buf_store_row4<kBufSc1>(T.wsb, rowb_off(G, T, 4, T.i, K2.rt, false), 0, Xa[0]);
+  STM_X_STORE(buf_store_row4<kXSc1>(T.wsb, rowb_off(G, T, 4, T.i, K2.rt, false), 0, Xa[0]));
   C.c2a = Xa[1];
-  buf_store_row4<0>(T.wsb, side_off(G, T, T.j, K2.rs[1]), 0, Xa[1]);
-  if (w < 3) {
-    C.c2b = Xa[2];
-    buf_store_row4<0>(T.wsb, side_off(G, T, T.j, K2.rs[2]), 0, Xa[2]);
-  }
-  buf_store_row4<kBufSc1>(T.wsb, rowb_off(G, T, 5, T.i, K3.rt, false), 0, Xb[0]);
+  STM_X_STORE(buf_store_row4<0>(T.wsb, side_off(G, T, T.j, K2.rs[1]), 0, Xa[1]));
+  C.c2b = sel_row(w < 3, Xa[2], Xa[1]);
+  STM_X_STORE(buf_store_row4<0>(T.wsb, side_off(G, T, T.j, K2.rs[2]), 0, C.c2b));  // (wave 3: no third piece, offset kNowhere)
+  STM_X_STORE(buf_store_row4<kXSc1>(T.wsb, rowb_off(G, T, 5, T.i, K3.rt, false), 0, Xb[0]));
 }
 
-__global__ __launch_bounds__(4 * 64, 4) void sgm_skew_rev_kernel(const float *__restrict__ cost_all,
+__global__ __launch_bounds__(4 * 64, STM_SKEW_REV_OCC) void sgm_skew_rev_kernel(const float *__restrict__ cost_all,
                                                                   const float *__restrict__ image_all,
                                                                   float *__restrict__ ws, const SkewArgs P) {
   __shared__ __attribute__((aligned(16))) float Ct[kT * kT * kD];
@@ -817,7 +873,7 @@ __global__ __launch_bounds__(4 * 64, 4) void sgm_skew_rev_kernel(const float *__
   const int nunits = G.batch * G.nTR;
   bool dead = false;
   RevCarry C;
-  Pre N;
+  RevPre N;
   for (;;) {
     __syncthreads();
     if (threadIdx.x == 0) s_unit = (int)atomicAdd(status + kTicketRev, 1u);
@@ -835,7 +891,11 @@ __global__ __launch_bounds__(4 * 64, 4) void sgm_skew_rev_kernel(const float *__
     const unsigned *prog_below = prog + prog_index(G, 0, b, below ? i + 1 : i);
     unsigned *prog_mine = prog + prog_index(G, 0, b, i);
     make_tile(T, G, i, G.nTC - 1);
-    prefetch_cost(N, G, T, image, L);
+    unsigned seen = 0;
+    if (L.w == 0 && below) wait_progress(prog_below, (unsigned)progress_needed(G, 0), seen, status, dead);
+    __syncthreads();
+    prefetch_cost(N.cost, G, T, image, L);
+    rev_bottoms(N, G, T, K1, K2, K3);
     Row<4> zero;
 #pragma unroll
     for (int k = 0; k < 4; ++k) zero.v[k] = 0.0f;
@@ -844,14 +904,13 @@ __global__ __launch_bounds__(4 * 64, 4) void sgm_skew_rev_kernel(const float *__
       const int j = G.nTC - 1 - jj;
       make_tile(T, G, i, j);
       make_tile(Tn, G, i, j > 0 ? j - 1 : 0);
-      stage_cost(N, Ct, Ip, L);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (L.w == 0 && below) wait_progress(prog_below, (unsigned)progress_needed(G, jj), status, dead);
+      stage_cost(N.cost, Ct, Ip, L);
+      // The band below is far enough ahead for the next tile's prefetch.
+      if (L.w == 0 && below) wait_progress(prog_below, (unsigned)progress_needed(G, jj), seen, status, dead);
       lds_barrier();
-      if (threadIdx.x == 0 && jj > 0) publish_progress(prog_mine, (unsigned)jj);
-      prefetch_cost(N, G, Tn, image, L);
-      if (T.gen) rev_tile<true>(P, T, K0, K1, K2, K3, C, Ct, Ip, X, L, lane);
-      else rev_tile<false>(P, T, K0, K1, K2, K3, C, Ct, Ip, X, L, lane);
+      unsigned *publish = jj > 0 ? prog_mine : nullptr;
+      if (T.gen) rev_tile<true>(P, T, Tn, K0, K1, K2, K3, C, N, image, Ct, Ip, X, L, lane, publish, (unsigned)jj);
+      else rev_tile<false>(P, T, Tn, K0, K1, K2, K3, C, N, image, Ct, Ip, X, L, lane, publish, (unsigned)jj);
       lds_barrier();  // (the next tile's staging overwrites the cost tile)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -896,7 +955,7 @@ int skew_run(const float *cost, const float *left, float *out, int32_t *disp, in
     return fail(STM_EHIP, "stm_sgm_f32 (skewed tiles): hipMemsetAsync failed");
   const long long units = (long long)batch * A.G.nTR;
   {
-    const long long wgs = (long long)cus * 4;
+    const long long wgs = (long long)cus * STM_SKEW_REV_OCC;
     const dim3 grid((unsigned)(units < wgs ? units : wgs)), block(4 * 64);
     hipLaunchKernelGGL(sgm_skew_rev_kernel, grid, block, 0, stream, cost, left, ws, A);
     const int rc = check_launch("stm_sgm_f32 (skewed tiles: reverse pass)");

@@ -110,6 +110,18 @@ bool shape_ok(int H, int W, int D, int batch, int flags) {
 
 SgmForm sgm_form(int H, int W, int D, int batch, int flags) {
   if ((flags & STM_SGM_SKEW) && !(flags & STM_SGM_PAIRED) && skew_covers(H, W, D, batch, flags)) return kSgmSkew;
+  // The skewed-tile form by default: large batches it covers.  Its two passes are pipelines of
+  // bands (a band starts three tiles behind the one it depends on): ~5 ms for a Teddy-sized image
+  // whatever the batch, so it needs several units (image, band) per workgroup to amortise that.
+  // Measured on MI355X (tools/gpu_jobs/forms_sweep.sh, Teddy 375 x 450 x 128, fused, ms per pair):
+  //   B =                      16     32     64     128    256
+  //   tiles behind walks       0.233  0.228  0.234  0.218
+  //   tiles behind sweeps      0.266  0.191  0.176  0.163  0.154
+  //   skewed tiles             0.360  0.201  0.148  0.132  0.127
+  if (!(flags & (STM_SGM_PAIRED | STM_SGM_TILED | STM_SGM_WALKS)) && skew_covers(H, W, D, batch, flags)) {
+    const int cus = device_cus();
+    if (cus > 0 && (long long)batch * ((H + kT - 1) / kT) >= 8ll * cus && W >= 64) return kSgmSkew;
+  }
   if (!shape_ok(H, W, D, batch, flags)) return kSgmPaired;
   TiledGeom G;
   long long total = 0, zero = 0;

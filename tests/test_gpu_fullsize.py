@@ -218,25 +218,29 @@ def test_config5_share_eight_1080p_pairs(device, oracle):
         assert torch.equal(wta(S1), fused_b[b]), "disparity pair %d" % b
 
 
-def test_teddy_large_batch_takes_the_tiled_form_and_matches_single_pairs(device, oracle):
+@pytest.mark.parametrize("form", ["auto", "tiled"])
+def test_teddy_large_batch_takes_the_tiled_form_and_matches_single_pairs(device, oracle, form):
     """A 48-pair Teddy batch is what the bench's primary workload looks like to the library: the
-    aggregation takes the tiled form (row sweeps + two-lines-per-wave tiles, workgroups owning
-    tile rows).  Pair 0 must hash to the reference digests, and every pair must equal its own
-    single-pair run (paired form), sum volume and fused disparity map, bit for bit."""
+    aggregation takes the skewed-tile form by default (two passes over sheared tiles, bands handed
+    over between workgroups); forced, the sweep-fed tiled form (row sweeps + two-lines-per-wave
+    tiles, workgroups owning tile rows).  Pair 0 must hash to the reference digests, and every pair
+    must equal its own single-pair run (paired form), sum volume and fused disparity map, bit for
+    bit."""
     import stereomatch
     from stereomatch import _native
     g = GOLDEN["teddy 375x450x128"]
     H, W, D, B = g["H"], g["W"], g["D"], 48
-    assert _native.lib().stm_sgm_form(H, W, D, B, 0) == _native.STM_SGM_FORM_SWEEPS, "the batch should take the sweep-fed tiled form"
+    want_form = _native.STM_SGM_FORM_SKEW if form == "auto" else _native.STM_SGM_FORM_SWEEPS
+    assert _native.lib().stm_sgm_form(H, W, D, B, _native.STM_SGM_FORMS[form]) == want_form
     pairs = [oracle.synthetic_pair(H, W, seed=s) for s in range(B)]
     Lb = torch.from_numpy(np.stack([p[0] for p in pairs])).to(device)
     Rb = torch.from_numpy(np.stack([p[1] for p in pairs])).to(device)
     ssd = stereomatch.cost.SSD(D)
-    sgm = stereomatch.aggregation.Semiglobal()
+    sgm = stereomatch.aggregation.Semiglobal(form=form)
     wta = stereomatch.disparity_reduce.WinnerTakesAll()
     Cb = ssd(Lb, Rb)
     Sb = sgm(Cb, Lb)
-    assert sgm.status() == 0
+    assert sgm.status() == 0 and sgm._last_form == want_form
     _, fused_b = sgm.aggregate_and_reduce(Cb, Lb)
     assert sgm.status() == 0
     assert digest16(Cb[0]) == g["ssd"] and digest16(Sb[0]) == g["sgm"]

@@ -26,7 +26,9 @@ def main():
     R = torch.from_numpy(np.ascontiguousarray(base[:, :, 39:39 + W])).to(dev)
     C = stereomatch.cost.SSD(D)(L, R)
     res = {}
-    for form in ("paired", "tiled", "walks"):
+    forms = os.environ.get("FORMS", "paired,tiled,walks,skew").split(",")
+    forms = [f for f in forms if f != "skew" or D == 128]
+    for form in forms:
         sgm = stereomatch.aggregation.Semiglobal(form=form)
         for fused in (True, False):
             vol = disp = None
@@ -49,7 +51,7 @@ def main():
                      8.0 * n / t / 1e6 / 8000.0, sgm.status()), flush=True)
         del sgm
         torch.cuda.empty_cache()
-    for form in ("tiled", "walks"):
+    for form in [f for f in forms if f != "paired" and "paired" in forms]:
         print(form, "fused disparities equal:", bool(torch.equal(res[("paired", True)], res[(form, True)])),
               " unfused volumes equal:", bool(torch.equal(res[("paired", False)].view(torch.int32),
                                                           res[(form, False)].view(torch.int32))))
