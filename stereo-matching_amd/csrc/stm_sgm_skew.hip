@@ -1,4 +1,4 @@
-// Semiglobal aggregation, SKEWED-TILE form (D = 128): two passes over sheared 8 x 8 tiles, each
+// Semiglobal aggregation, SKEWED-TILE form (D = 128, 256): two passes over sheared 8 x 8 tiles, each
 // reading the cost volume once; the four directions of a pass are carried from tile to tile
 // (registers inside a band, row border states + progress counters between bands).  Geometry,
 // chains and the reasoning: stm_sgm_skew_index.h.
@@ -9,8 +9,10 @@
 // diagonal families (Q6: line_counts).  Same float operations in the same order as the other
 // forms -> identical bits (tests/test_gpu_sgm_skew.py: against the oracle and the paired form).
 //
-// Two pixels per wave (stm_sgm_step.h, sgm_step_h2*): lanes 0-31 one pixel's 128 disparities,
-// lanes 32-63 another's; a half-wave owns one CHAIN (8 slots) per pair.  Four waves per tile.
+// D = 128: two pixels per wave (stm_sgm_step.h, sgm_step_h2*): lanes 0-31 one pixel's 128
+// disparities, lanes 32-63 another's; a half-wave owns one CHAIN (8 slots) per pair, four waves
+// per tile.  D = 256: one pixel per wave, a wave owns one chain per pair, eight waves per tile.
+// The kernels (stm_sgm_skew_body.h) are compiled once per D: stm_sgm_skew_d128.hip, _d256.hip.
 //
 //   sgm_skew_rev_kernel  bands bottom-up, tiles right-to-left; left / up / up-left / up-right.
 //                        LDS: the cost tile (32 KB): four workgroups per CU.
@@ -27,903 +29,13 @@
 // the order "band 0 of every image, band 1 of every image, ...": the band a unit waits for has
 // a lower ticket, so it is held by a workgroup that runs or is done -- no residency requirement,
 // no deadlock.  Waits are bounded (~2 s -> status word), like the sweeps'.
-#include "stm_sgm_tile_d128.h"
-#include "stm_sgm_skew_index.h"
-#include "stm_sgm_skew_launch.h"
+#include "stm_sgm_skew_launch.h"  // (stm_common.h first: the index header needs the HIP runtime's qualifiers)
 
 namespace stm {
-namespace {
-
-using namespace skew;
-using std::integral_constant;
-
-#ifndef STM_SKEW_FWD_PREFETCH_AT
-#define STM_SKEW_FWD_PREFETCH_AT 2  // the next tile's cost rows are requested behind pair 1 / pair 2
-#endif
-#ifndef STM_SKEW_REV_OCC
-#define STM_SKEW_REV_OCC 2  // workgroups of the reverse pass per CU (registers: 512 / (4 x this) per lane)
-#endif
-// Timing experiments (tools/build_skew_variants.sh; results are wrong with any of them):
-#ifdef STM_SKEW_X_PLAIN
-constexpr int kXSc1 = 0;
-#else
-constexpr int kXSc1 = kBufSc1;
-#endif
-#ifdef STM_SKEW_X_NOSTORE
-#define STM_X_STORE(...) do {} while (0)
-#else
-#define STM_X_STORE(...) __VA_ARGS__
-#endif
-constexpr int kD = 128;
-constexpr int kRowBytes = kD * 4;            // one pixel's disparities
-constexpr int kSumPixBytes = st_stride(kD) * 4;
-constexpr int kIpW = kT + 4;                 // intensity patch: u in [-2, 9], r in [-1, 8]
-constexpr int kIpN = kIpW * (kT + 2);
-
-struct SkewArgs {
-  SkewGeom G;
-  float p1, p2;
-  int dlim;
-  int true_paths;
-};
-
-struct LaneId {
-  int w, half, hl, d0, hl16;
-};
-
-// Per-lane constants of a pair: the lane's chain.  Pieces are in SLOT order (which for pair 1's
-// second half-wave is B before A, so that both halves of a wave change piece at the same slot).
-struct PK {
-  int pix[3];       // r * 8 + u of the first slot of each piece
-  unsigned ft;      // forward pass: top entry of the forward chain (row border states; relative)
-  unsigned fb;      // forward pass: bottom exit of the forward chain
-  unsigned ie[3];   // forward pass: entry of the inverse chain per piece: relative | 1 = side block
-  unsigned rb;      // reverse pass: bottom entry of the inverse chain
-  unsigned rt;      // reverse pass: top exit of the inverse chain
-  unsigned rs[3];   // reverse pass: left exit per piece (side block; kNowhere: none)
-  bool carry_first; // pair 1: the first piece in slot order is the one that enters from the left
-  bool restart1;    // the second piece begins at an entry state (false: the main diagonal continues)
-};
-
-// Relative byte offsets: a row border state at image column x = 8 j + xr is ((xr + 8) * D + d0) * 4
-// from the state of column 8 j - 8 in the same line; a side state is (idx * D + d0) * 4 into its block.
-__device__ __forceinline__ unsigned rel_row(int xr, int d0) { return (unsigned)(((xr + kT) * kD + d0) * 4); }
-__device__ __forceinline__ unsigned rel_side(int idx, int d0) { return (unsigned)((idx * kD + d0) * 4) | 1u; }
-
-template <int PHASE>
-__device__ __forceinline__ void pk_init(PK &K, const LaneId &L) {
-  const int d0 = L.d0;
-  K.carry_first = false;
-  K.restart1 = true;
-  K.ft = K.fb = K.rb = K.rt = kNowhere;
-#pragma unroll
-  for (int q = 0; q < 3; ++q) { K.pix[q] = 0; K.ie[q] = kNowhere; K.rs[q] = kNowhere; }
-  if constexpr (PHASE == 0) {
-    const int k = 2 * L.w + L.half;
-    K.pix[0] = k * kT;
-    K.ie[0] = rel_side(side_idx_left(k), d0);
-    K.rs[0] = rel_side(side_idx_left(k), d0);
-  } else if constexpr (PHASE == 3) {
-    const int k = 2 * L.w + L.half;
-    K.pix[0] = k;
-    K.ft = rel_row(k + 1, d0);      // state of down-left after (x + 1, y0 - 1)
-    K.fb = rel_row(k - 7, d0);      // ... after the column's last pixel (k, 7): x = 8 j + k - 7
-    K.ie[0] = rel_row(k - 8, d0);   // up-right after (x - 1, y0 + 8)
-    K.rb = K.ie[0];
-    K.rt = rel_row(k, d0);          // up-right after (k, 0)
-  } else if constexpr (PHASE == 1) {
-    const bool main_diag = L.half == 1 && L.w == 3;
-    const int c = L.half == 0 ? L.w + 1 : (main_diag ? 0 : 7 - L.w);
-    const Chain ch = chain_of(1, c);
-    const int pa = ch.p[0].r * kT + ch.p[0].u, pb = ch.p[1].r * kT + ch.p[1].u;
-    if (main_diag) {
-      K.pix[0] = 0; K.pix[1] = 4 * kT + 4;
-      K.restart1 = false;
-      K.ft = rel_row(0, d0); K.fb = rel_row(0, d0);
-      K.ie[1] = rel_row(0, d0);
-      K.rb = rel_row(0, d0); K.rt = rel_row(0, d0);
-    } else {
-      K.carry_first = L.half == 1;
-      K.pix[0] = K.carry_first ? pb : pa;
-      K.pix[1] = K.carry_first ? pa : pb;
-      K.ft = rel_row(c, d0);        // down after (x = 8 j + c, y0 - 1)
-      K.fb = rel_row(c - 8, d0);    // ... after B's last pixel (c - 1, 7): x = 8 j + c - 8
-      const unsigned side = rel_side(side_idx_up(kT - c), d0), bot = rel_row(c - 8, d0);
-      K.ie[0] = K.carry_first ? bot : side;
-      K.ie[1] = K.carry_first ? side : bot;
-      K.rb = bot;
-      K.rt = rel_row(c, d0);
-      K.rs[0] = K.carry_first ? side : kNowhere;  // B leaves to the left at (0, 8 - c)
-      K.rs[1] = K.carry_first ? kNowhere : side;
-    }
-  } else {
-    const int c0 = 7 - (2 * L.w + L.half);
-    const Chain ch = chain_of(2, c0);
-    int ul = 0;  // u of the chain's last pixel (row 7)
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      if (q < ch.np) {
-        K.pix[q] = ch.p[q].r * kT + ch.p[q].u;
-        const int ue = ch.p[q].u + 2 * (ch.p[q].n - 1), re = ch.p[q].r + ch.p[q].n - 1;  // its last pixel
-        if (q == ch.np - 1) {
-          ul = ue;
-        } else {
-          // the inverse chain enters from (ue + 2, re + 1), pixel (ue - 6, re + 1) of the tile on the right
-          K.ie[q] = rel_side(side_idx_upleft(ue + 2 - kT, re + 1), d0);
-        }
-        if (q > 0) K.rs[q] = rel_side(side_idx_upleft(ch.p[q].u, ch.p[q].r), d0);  // leaves to the left at its first pixel
-      }
-    }
-    K.ft = rel_row(c0 - 1, d0);           // down-right after (x - 1, y0 - 1)
-    K.fb = rel_row(ul - 7, d0);           // ... after the last pixel (ul, 7)
-    K.ie[ch.np - 1] = rel_row(ul - 6, d0);  // up-left after (x + 1, y0 + 8)
-    K.rb = K.ie[ch.np - 1];
-    K.rt = rel_row(c0, d0);               // up-left after (c0, 0)
-  }
-}
-
-// Where a tile's accesses go: descriptors over the image's cost volume, output and workspace
-// block, and the tile's terms of the offsets.
-struct TileCtx {
-  BufRsrc cost, out, wsb;
-  int i, j;         // band, tile column
-  int x0, y0;
-  bool gen;         // not a fast tile: validity per lane
-};
-
-// Byte offset (inside the image's workspace block) of a row border state given its relative
-// offset; kNowhere when it does not exist (gen tiles only).
-__device__ __forceinline__ unsigned rowb_off(const SkewGeom &G, const TileCtx &T, int dir, int t, unsigned rel,
-                                             bool need_row7) {
-  if (rel >= kNowhere) return kNowhere;
-  if (!T.gen) return rel + (unsigned)(rowb_in_img(G, dir, t, T.x0 - kT) * 4);
-  const int xr = (int)(rel / (unsigned)kRowBytes) - kT, x = T.x0 + xr;
-  bool ok = rel != kNowhere && x >= 0 && x < G.W && t >= 0 && t < G.nTR;
-  if (need_row7) ok = ok && kT * t + kT - 1 < G.H;
-  return ok ? (unsigned)(rowb_in_img(G, dir, t, x) * 4) + rel % (unsigned)kRowBytes : kNowhere;
-}
-__device__ __forceinline__ unsigned side_off(const SkewGeom &G, const TileCtx &T, int jb, unsigned rel) {
-  if (rel >= kNowhere) return kNowhere;
-  const unsigned r = rel & ~1u;
-  if (!T.gen) return r + (unsigned)(side_in_img(G, T.i, jb, 0) * 4);
-  const bool ok = jb >= 1 && jb < G.nTC;
-  return ok ? r + (unsigned)(side_in_img(G, T.i, jb, 0) * 4) : kNowhere;
-}
-// An inverse-chain entry of the forward pass: side block of tile j + 1 or row states of band i + 1.
-__device__ __forceinline__ unsigned fwd_ie_off(const SkewGeom &G, const TileCtx &T, int dir, unsigned e) {
-  if (e >= kNowhere) return kNowhere;
-  if (!T.gen) {
-    const unsigned base = (e & 1u) ? (unsigned)(side_in_img(G, T.i, T.j + 1, 0) * 4) : (unsigned)(rowb_in_img(G, dir, T.i + 1, T.x0 - kT) * 4);
-    return (e & ~1u) + base;
-  }
-  return (e & 1u) ? side_off(G, T, T.j + 1, e) : rowb_off(G, T, dir, T.i + 1, e, false);
-}
-
-// ---- cost tile, intensities ---------------------------------------------------------------------
-// Half-wave (w, half) stages tile row r = 2 w + half: pixels u = 0..7 at x = x0 + u - r, y = y0 + r,
-// clamped into the image (a clamped pixel is never used).
-struct Pre {
-  Row<4> cpre[kT];
-  float ipre;
-};
-__device__ __forceinline__ void prefetch_cost(Pre &P, const SkewGeom &G, const TileCtx &T, const float *image,
-                                              const LaneId &L) {
-  const int r = 2 * L.w + L.half;
-  if (!T.gen) {
-    const unsigned base = ((unsigned)((T.y0 + r) * G.W + T.x0 - r) * (unsigned)kD + (unsigned)L.d0) * 4u;
-#pragma unroll
-    for (int u = 0; u < kT; ++u) P.cpre[u] = buf_load_row4<0>(T.cost, base + (unsigned)(u * kRowBytes), 0);
-  } else {
-    const int y = imin_(T.y0 + r, G.H - 1);
-#pragma unroll
-    for (int u = 0; u < kT; ++u) {
-      const int x = imin_(imax_(T.x0 + u - r, 0), G.W - 1);
-      P.cpre[u] = buf_load_row4<0>(T.cost, ((unsigned)(y * G.W + x) * (unsigned)kD + (unsigned)L.d0) * 4u, 0);
-    }
-  }
-  const int e = imin_((int)threadIdx.x, kIpN - 1);
-  const int rr = e / kIpW - 1, uu = e % kIpW - 2;
-  const int y = imin_(imax_(T.y0 + rr, 0), G.H - 1), x = imin_(imax_(T.x0 + uu - rr, 0), G.W - 1);
-  P.ipre = image[y * G.W + x];
-}
-__device__ __forceinline__ void stage_cost(const Pre &P, float *Ct, float *Ip, const LaneId &L) {
-  const int r = 2 * L.w + L.half;
-#pragma unroll
-  for (int u = 0; u < kT; ++u) h2_lds_store(Ct, (r * kT + u) * kRowBytes + L.hl16, P.cpre[u]);
-  if (threadIdx.x < kIpN) Ip[threadIdx.x] = P.ipre;
-}
-
-// Penalties of a chain: lane l of every 16-lane row holds the one of slot l & 7 -- lanes 0-7 of
-// chain A (phase PA, direction sign SA: -1 = the step from the forward predecessor, +1 = from the
-// forward successor, i.e. the inverse chain), lanes 8-15 of chain B.
-template <int PA, int SA, int PB, int SB>
-__device__ __forceinline__ float chain_penalties(const PK &KA, int naA, int nbA, const PK &KB, int naB, int nbB,
-                                                 const float *Ip, float p1, float p2, int lane) {
-  const int s = lane & 7;
-  const bool second = (lane >> 3) & 1;
-  const int na = second ? naB : naA, nb = second ? nbB : nbA;
-  const int q = s < na ? 0 : (s < nb ? 1 : 2);
-  const int start = q == 0 ? 0 : (q == 1 ? na : nb);
-  const int pixA = KA.pix[0] * (q == 0) + KA.pix[1] * (q == 1) + KA.pix[2] * (q == 2) + (s - start) * tile_pstep(PA);
-  const int pixB = KB.pix[0] * (q == 0) + KB.pix[1] * (q == 1) + KB.pix[2] * (q == 2) + (s - start) * tile_pstep(PB);
-  const int pix = second ? pixB : pixA;
-  const int du = second ? SB * tile_du(PB) : SA * tile_du(PA), dr = second ? SB * tile_dr(PB) : SA * tile_dr(PA);
-  const int u = pix & (kT - 1), r = pix >> 3;
-  return sgm_penalty(Ip[(r + 1) * kIpW + u + 2], Ip[(r + dr + 1) * kIpW + u + du + 2], p1, p2);
-}
-
-// Per-slot flags of a gen tile.
-struct SlotFlags {
-  bool valid, begin_f, begin_i;
-};
-template <int PHASE>
-__device__ __forceinline__ SlotFlags slot_flags(const SkewGeom &G, const TileCtx &T, int pix) {
-  const int u = pix & (kT - 1), r = pix >> 3;
-  const int x = T.x0 + u - r, y = T.y0 + r;
-  SlotFlags f;
-  f.valid = in_image(G, x, y);
-  f.begin_f = f.valid && !in_image(G, x - img_dx(PHASE), y - img_dy(PHASE));
-  f.begin_i = f.valid && !in_image(G, x + img_dx(PHASE), y + img_dy(PHASE));
-  return f;
-}
-__device__ __forceinline__ Row<4> sel_row(bool c, const Row<4> &a, const Row<4> &b) {
-  Row<4> r;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) r.v[k] = c ? a.v[k] : b.v[k];
-  return r;
-}
-
-// =====================================================================================
-// Forward pass: one pair of a tile for one wave (two chains): both chains of the pair stepped
-// together (slot s of the forward chain with slot 7 - s of the inverse chain), the update
-// S = ((S + [I x pre]) + F) + I x inv of the sum tile from the fifth step on (stm_sgm_tile_h2.hip).
-//   Ef / Ei   entry states per piece (slot order); Xf: the forward chain's state after each piece.
-//   cls       count class of the tile for this pair (skew::count_class); gen tiles pass 3.
-// =====================================================================================
-template <int PHASE, int NA, int NB, int FINAL, bool GEN, typename Between>
-__device__ __forceinline__ void fwd_pair(const PK &K, const Row<4> (&Ef)[3], const Row<4> (&Ei)[3], Row<4> (&Xf)[3],
-                                         int cls, const SkewGeom &G, const TileCtx &T, int true_paths,
-                                         const float *Ct, float *St, float pen, StepCtxH2 &X, const LaneId &L,
-                                         Between between) {
-  constexpr int pstep = tile_pstep(PHASE);
-  constexpr int NP = NB < kT ? 3 : (NA < kT ? 2 : 1);
-  StepCtxH2 XI = X;
-  const int hl16 = L.hl16;
-  const bool run_inv = cls != 0;
-  const bool counted = PHASE >= 2 && cls == 3;
-  auto pix_of = [&](auto s_) {
-    constexpr int s = decltype(s_)::value;
-    constexpr int q = s < NA ? 0 : (s < NB ? 1 : 2), st = q == 0 ? 0 : (q == 1 ? NA : NB);
-    return K.pix[q] + (s - st) * pstep;
-  };
-  auto addr = [&](auto s_) { return pix_of(s_) * kRowBytes + hl16; };
-  auto saddr = [&](auto s_) { return pix_of(s_) * kSumPixBytes + hl16; };
-  // Counts of the lane's pieces (cls >= 2): per piece, from its first pixel's image coordinates.
-  int pre[3] = {0, 0, 0}, inv[3] = {1, 1, 1};
-  if (PHASE >= 2 && cls >= 2) {
-#pragma unroll
-    for (int q = 0; q < NP; ++q) {
-      const int u = K.pix[q] & (kT - 1), r = K.pix[q] >> 3;
-      const tiled::Counts c = line_counts(PHASE, T.x0 + u - r, T.y0 + r, G.H, G.W, true_paths);
-      pre[q] = c.pre;
-      inv[q] = c.inv;
-    }
-  }
-  Row<4> LF[kT], LI[kT];
-  Row<4> pf = Ef[0];
-  Row<4> pi = Ei[NP - 1];
-  auto update = [&](auto s_, Row<4> &acc) {
-    constexpr int s = decltype(s_)::value;
-    constexpr int q = s < NA ? 0 : (s < NB ? 1 : 2);
-    if (PHASE == 0) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) acc.v[k] = 0.0f;
-    }
-    f32x2 lo = f32x2{acc.v[0], acc.v[1]}, hi = f32x2{acc.v[2], acc.v[3]};
-    const f32x2 ilo = f32x2{LI[s].v[0], LI[s].v[1]}, ihi = f32x2{LI[s].v[2], LI[s].v[3]};
-    if (counted) {
-      const int pr = pre[q], iv = inv[q];
-      const int pa = __builtin_amdgcn_readlane(pr, 0), pb = __builtin_amdgcn_readlane(pr, 32);
-      const int ia = __builtin_amdgcn_readlane(iv, 0), ib = __builtin_amdgcn_readlane(iv, 32);
-      for (int r = 0, n = pa > pb ? pa : pb; r < n; ++r) {
-        const f32x2 l2 = lo + ilo, h2 = hi + ihi;
-        lo = r < pr ? l2 : lo;
-        hi = r < pr ? h2 : hi;
-      }
-      lo = lo + f32x2{LF[s].v[0], LF[s].v[1]};
-      hi = hi + f32x2{LF[s].v[2], LF[s].v[3]};
-      for (int r = 0, n = ia > ib ? ia : ib; r < n; ++r) {
-        const f32x2 l2 = lo + ilo, h2 = hi + ihi;
-        lo = r < iv ? l2 : lo;
-        hi = r < iv ? h2 : hi;
-      }
-    } else {
-      lo = lo + f32x2{LF[s].v[0], LF[s].v[1]};
-      hi = hi + f32x2{LF[s].v[2], LF[s].v[3]};
-      if (run_inv) {
-        const f32x2 lo2 = lo + ilo, hi2 = hi + ihi;
-        const bool r = PHASE < 2 || inv[q] != 0;
-        lo = r ? lo2 : lo;
-        hi = r ? hi2 : hi;
-      }
-    }
-    acc.v[0] = lo.x; acc.v[1] = lo.y; acc.v[2] = hi.x; acc.v[3] = hi.y;
-    if (PHASE < 3 || FINAL != 0) h2_lds_store(St, saddr(s_), acc);
-  };
-  // Pair 3: the finished sum of a slot leaves (unless only the winners are wanted).
-  auto finish = [&](auto s_, const Row<4> &acc) {
-    if constexpr (PHASE == 3 && FINAL != 2) {
-      const int pix = pix_of(s_);
-      const int u = pix & (kT - 1), r = pix >> 3;
-      const int x = T.x0 + u - r, y = T.y0 + r;
-      const unsigned off = (!GEN || in_image(G, x, y)) ? ((unsigned)(y * G.W + x) * (unsigned)kD + (unsigned)L.d0) * 4u : kNowhere;
-      buf_store_row4<0>(T.out, off, 0, acc);
-    }
-  };
-  auto sum_of = [&](auto s_) {
-    Row<4> r;
-    if (PHASE != 0) r = h2_lds_row(St, saddr(s_));
-    else r = Ef[0];  // (unused: any defined value)
-    return r;
-  };
-  auto note_exit = [&](auto s_) {
-    constexpr int s = decltype(s_)::value;
-    if constexpr (s == NA - 1) Xf[0] = pf;
-    if constexpr (NA < kT ? s == NB - 1 : s == kT - 1) Xf[1] = pf;  // (a piece the chain does not have: a defined value)
-    if constexpr (s == kT - 1) Xf[2] = pf;
-  };
-  if (run_inv) {
-    Row<4> cf = h2_lds_row(Ct, addr(integral_constant<int, 0>()));
-    Row<4> ci = h2_lds_row(Ct, addr(integral_constant<int, kT - 1>()));
-    Row<4> sa, sb;
-    auto both = [&](auto s_) {
-      constexpr int s = decltype(s_)::value, r = kT - 1 - s;
-      if constexpr (NA < kT && s == NA) pf = PHASE == 1 ? sel_row(K.restart1, Ef[1], pf) : Ef[1];
-      if constexpr (NB < kT && s == NB) pf = Ef[2];
-      if constexpr (NB < kT && r == NB - 1) pi = Ei[1];
-      if constexpr (NA < kT && r == NA - 1) pi = PHASE == 1 ? sel_row(K.restart1, Ei[0], pi) : Ei[0];
-      Row<4> cfn = cf, cin = ci;
-      if constexpr (s < kT - 1) {
-        cfn = h2_lds_row(Ct, addr(integral_constant<int, s + 1>()));
-        cin = h2_lds_row(Ct, addr(integral_constant<int, r - 1>()));
-      }
-      if constexpr (s == kT / 2) {
-        between();
-        sa = sum_of(integral_constant<int, s>());
-        sb = sum_of(integral_constant<int, r>());
-      }
-      sgm_step_h2x2<s, 8 + r>(pf, cf, pi, ci, pen, X, XI);
-      if constexpr (GEN) {
-        const SlotFlags ff = slot_flags<PHASE>(G, T, pix_of(s_)), fi = slot_flags<PHASE>(G, T, pix_of(integral_constant<int, r>()));
-        pf = sel_row(ff.begin_f, cf, pf);
-        pi = sel_row(fi.begin_i, ci, pi);
-      }
-      LF[s] = pf;
-      LI[r] = pi;
-      note_exit(s_);
-      cf = cfn;
-      ci = cin;
-      if constexpr (s >= kT / 2) {
-        update(integral_constant<int, s>(), sa);
-        finish(integral_constant<int, s>(), sa);
-        update(integral_constant<int, r>(), sb);
-        finish(integral_constant<int, r>(), sb);
-        if constexpr (s < kT - 1) {
-          sa = sum_of(integral_constant<int, s + 1>());
-          sb = sum_of(integral_constant<int, r - 1>());
-        }
-      }
-    };
-    both(integral_constant<int, 0>()); both(integral_constant<int, 1>());
-    both(integral_constant<int, 2>()); both(integral_constant<int, 3>());
-    both(integral_constant<int, 4>()); both(integral_constant<int, 5>());
-    both(integral_constant<int, 6>()); both(integral_constant<int, 7>());
-  } else {
-    // No inverse pass counts anywhere in this tile (Q6): the forward chain alone.
-    between();
-    Row<4> sa = sum_of(integral_constant<int, 0>());
-    auto fstep = [&](auto s_) {
-      constexpr int s = decltype(s_)::value;
-      if constexpr (NA < kT && s == NA) pf = PHASE == 1 ? sel_row(K.restart1, Ef[1], pf) : Ef[1];
-      if constexpr (NB < kT && s == NB) pf = Ef[2];
-      const Row<4> c = h2_lds_row(Ct, addr(s_));
-      pf = sgm_step_h2<s>(pf, c, pen, X);
-      LF[s] = pf;
-      LI[s] = pf;  // (not added: inv == 0)
-      note_exit(s_);
-      update(s_, sa);
-      finish(s_, sa);
-      if constexpr (s < kT - 1) sa = sum_of(integral_constant<int, s + 1>());
-    };
-    fstep(integral_constant<int, 0>()); fstep(integral_constant<int, 1>());
-    fstep(integral_constant<int, 2>()); fstep(integral_constant<int, 3>());
-    fstep(integral_constant<int, 4>()); fstep(integral_constant<int, 5>());
-    fstep(integral_constant<int, 6>()); fstep(integral_constant<int, 7>());
-  }
-}
-
-template <int PHASE, int FINAL, bool GEN, typename Between>
-__device__ __forceinline__ void fwd_pair_w(int w, const PK &K, const Row<4> (&Ef)[3], const Row<4> (&Ei)[3],
-                                           Row<4> (&Xf)[3], int cls, const SkewGeom &G, const TileCtx &T,
-                                           int true_paths, const float *Ct, float *St, float pen, StepCtxH2 &X,
-                                           const LaneId &L, Between between) {
-#define STM_FWD_PAIR(NA, NB) \
-  fwd_pair<PHASE, NA, NB, FINAL, GEN>(K, Ef, Ei, Xf, cls, G, T, true_paths, Ct, St, pen, X, L, between)
-  if constexpr (PHASE == 0 || PHASE == 3) {
-    STM_FWD_PAIR(kT, kT);
-  } else if constexpr (PHASE == 1) {
-    switch (w) {
-      case 0: STM_FWD_PAIR(7, kT); break;
-      case 1: STM_FWD_PAIR(6, kT); break;
-      case 2: STM_FWD_PAIR(5, kT); break;
-      default: STM_FWD_PAIR(4, kT); break;
-    }
-  } else {
-    switch (w) {
-      case 0: STM_FWD_PAIR(1, 5); break;
-      case 1: STM_FWD_PAIR(2, 6); break;
-      case 2: STM_FWD_PAIR(3, 7); break;
-      default: STM_FWD_PAIR(4, kT); break;
-    }
-  }
-#undef STM_FWD_PAIR
-}
-// Slots at which wave w's chains of a pair change piece.
-__device__ __forceinline__ int na_of(int phase, int w) { return phase == 1 ? 7 - w : (phase == 2 ? w + 1 : kT); }
-__device__ __forceinline__ int nb_of(int phase, int w) { return phase == 2 && w < 3 ? w + 5 : kT; }
-
-// =====================================================================================
-// Reverse pass: the inverse chains of TWO pairs of a tile for one wave, stepped together (slot
-// 7 - s of both).  Ea / Eb: entry states per piece; Xa / Xb: the chain's state after each piece
-// (in slot order: X[q] is the state after the piece's FIRST slot, where the inverse chain leaves it).
-// =====================================================================================
-template <int PA, int NAA, int NBA, int PB, int NAB, int NBB, bool GEN>
-__device__ __forceinline__ void rev_pairs(const PK &KA, const Row<4> (&Ea)[3], Row<4> (&Xa)[3], const PK &KB,
-                                          const Row<4> (&Eb)[3], Row<4> (&Xb)[3], const SkewGeom &G,
-                                          const TileCtx &T, const float *Ct, float pen, StepCtxH2 &X,
-                                          const LaneId &L) {
-  constexpr int NPA = NBA < kT ? 3 : (NAA < kT ? 2 : 1), NPB = NBB < kT ? 3 : (NAB < kT ? 2 : 1);
-  StepCtxH2 XB = X;
-  const int hl16 = L.hl16;
-  auto pix_a = [&](auto s_) {
-    constexpr int s = decltype(s_)::value;
-    constexpr int q = s < NAA ? 0 : (s < NBA ? 1 : 2), st = q == 0 ? 0 : (q == 1 ? NAA : NBA);
-    return KA.pix[q] + (s - st) * tile_pstep(PA);
-  };
-  auto pix_b = [&](auto s_) {
-    constexpr int s = decltype(s_)::value;
-    constexpr int q = s < NAB ? 0 : (s < NBB ? 1 : 2), st = q == 0 ? 0 : (q == 1 ? NAB : NBB);
-    return KB.pix[q] + (s - st) * tile_pstep(PB);
-  };
-  Row<4> pa = Ea[NPA - 1], pb = Eb[NPB - 1];
-  Row<4> ca = h2_lds_row(Ct, pix_a(integral_constant<int, kT - 1>()) * kRowBytes + hl16);
-  Row<4> cb = h2_lds_row(Ct, pix_b(integral_constant<int, kT - 1>()) * kRowBytes + hl16);
-  auto both = [&](auto r_) {
-    constexpr int r = decltype(r_)::value;
-    if constexpr (NBA < kT && r == NBA - 1) pa = Ea[1];
-    if constexpr (NAA < kT && r == NAA - 1) pa = PA == 1 ? sel_row(KA.restart1, Ea[0], pa) : Ea[0];
-    if constexpr (NBB < kT && r == NBB - 1) pb = Eb[1];
-    if constexpr (NAB < kT && r == NAB - 1) pb = PB == 1 ? sel_row(KB.restart1, Eb[0], pb) : Eb[0];
-    Row<4> can = ca, cbn = cb;
-    if constexpr (r > 0) {
-      can = h2_lds_row(Ct, pix_a(integral_constant<int, r - 1>()) * kRowBytes + hl16);
-      cbn = h2_lds_row(Ct, pix_b(integral_constant<int, r - 1>()) * kRowBytes + hl16);
-    }
-    sgm_step_h2x2<r, 8 + r>(pa, ca, pb, cb, pen, X, XB);
-    if constexpr (GEN) {
-      const SlotFlags fa = slot_flags<PA>(G, T, pix_a(r_)), fb = slot_flags<PB>(G, T, pix_b(r_));
-      pa = sel_row(fa.begin_i, ca, pa);
-      pb = sel_row(fb.begin_i, cb, pb);
-    }
-    // (pieces a chain does not have get a defined value too)
-    if constexpr (r == 0) Xa[0] = pa;
-    if constexpr (NAA < kT ? r == NAA : r == 0) Xa[1] = pa;
-    if constexpr (NBA < kT ? r == NBA : r == 0) Xa[2] = pa;
-    if constexpr (r == 0) Xb[0] = pb;
-    if constexpr (NAB < kT ? r == NAB : r == 0) Xb[1] = pb;
-    if constexpr (NBB < kT ? r == NBB : r == 0) Xb[2] = pb;
-    ca = can;
-    cb = cbn;
-  };
-  both(integral_constant<int, 7>()); both(integral_constant<int, 6>());
-  both(integral_constant<int, 5>()); both(integral_constant<int, 4>());
-  both(integral_constant<int, 3>()); both(integral_constant<int, 2>());
-  both(integral_constant<int, 1>()); both(integral_constant<int, 0>());
-}
-
-// ---- progress counters --------------------------------------------------------------------------
-// Waits (one wave) until *p >= need.  Bounded like the sweeps' waits: ~2 s, then the status word is
-// set and nobody waits again.
-// `seen`: the counter's value when this wave last looked (it only grows): no load at all while
-// that already suffices -- a band's owner that runs well behind its neighbour polls once per
-// several tiles.
-__device__ __forceinline__ void wait_progress(const unsigned *p, unsigned need, unsigned &seen, unsigned *status,
-                                              bool &dead) {
-#ifdef STM_SKEW_NOWAIT  // (timing experiment: results are wrong)
-  return;
-#endif
-  if (dead || seen >= need) return;
-  seen = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (seen >= need) return;
-  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-  for (;;) {
-    __builtin_amdgcn_s_sleep(8);
-    seen = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (seen >= need) return;
-    if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { dead = true; return; }
-    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
-      dead = true;
-      if ((threadIdx.x & 63) == 0) atomicOr(status, STM_SGM_STATUS_TIMEOUT);
-      return;
-    }
-  }
-}
-__device__ __forceinline__ void publish_progress(unsigned *p, unsigned value) {
-  __hip_atomic_store(p, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Winner takes all of the finished sum tile (tile_wta_lds with the sheared pixel positions).
-__device__ __forceinline__ void skew_wta(const float *St, int wave, int lane, const SkewGeom &G, int x0, int y0,
-                                         int32_t *__restrict__ disp) {
-  constexpr int LP = 4, NJ = kD / (LP * 4);
-  typedef float v4f __attribute__((ext_vector_type(4)));
-  const int pix = wave * 16 + lane / LP, r = lane % LP;
-  const float *p = St + pix * st_stride(kD) + r * 4;
-  float best = __builtin_inff();
-  int idxk = 0;
-  bool nan0 = false;
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const v4f q = *reinterpret_cast<const v4f *>(p + j * LP * 4);
-    const float v[4] = {q.x, q.y, q.z, q.w};
-    if (j == 0) nan0 = r == 0 && v[0] != v[0];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const bool lt = v[e] < best;
-      best = lt ? v[e] : best;
-      idxk = lt ? j * LP * 4 + e : idxk;
-    }
-  }
-  float m = best;
-  m = vmin_f32(m, dpp_f32<0xb1>(m, m));
-  m = vmin_f32(m, dpp_f32<0x4e>(m, m));
-  int k = best == m ? idxk + r * 4 : 0x7fffffff;
-  k = nan0 ? 0 : k;
-  int t;
-  t = dpp_i32<0xb1>(k, k); k = t < k ? t : k;
-  t = dpp_i32<0x4e>(k, k); k = t < k ? t : k;
-  const int u = pix & (kT - 1), rr = pix >> 3;
-  const int x = x0 + u - rr, y = y0 + rr;
-  if (r == 0 && in_image(G, x, y)) disp[y * G.W + x] = k;
-}
-
-// =====================================================================================
-// Forward pass.
-// =====================================================================================
-struct FwdCarry {
-  Row<4> c0, c1, c2a, c2b;  // pair 0; pair 1 (A -> B); pair 2 (P0 -> P1, P1 -> P2)
-};
-// Entries of the NEXT tile requested during a tile: pair 0's inverse entry, pair 1's three.
-struct FwdPre {
-  Pre cost;
-  Row<4> e0i, e1t, e1i[2];
-};
-
-template <int FINAL, bool GEN>
-__device__ __forceinline__ void fwd_tile(const SkewArgs &P, const TileCtx &T, const TileCtx &Tn, bool have_next,
-                                         const PK &K0, const PK &K1, const PK &K2, const PK &K3, FwdCarry &C,
-                                         FwdPre &N, const float *image, float *Ct, float *St, const float *Ip,
-                                         StepCtxH2 &X, const LaneId &L, int lane, unsigned *publish) {
-  const SkewGeom &G = P.G;
-  const int w = L.w;
-  const int cls2 = GEN ? 3 : count_class(2, G, T.i, T.j, P.true_paths);
-  const int cls3 = GEN ? 3 : count_class(3, G, T.i, T.j, P.true_paths);
-  // Entries of pairs 2 and 3 (a global load takes longer than a pair: pairs 0 and 1 cover them).
-  const Row<4> e2t = buf_load_row4<kXSc1>(T.wsb, rowb_off(G, T, 1, T.i - 1, K2.ft, false), 0);
-  const Row<4> e3t = buf_load_row4<kXSc1>(T.wsb, rowb_off(G, T, 2, T.i - 1, K3.ft, false), 0);
-  Row<4> Ei2[3], Ei3[3];
-#pragma unroll
-  for (int q = 0; q < 3; ++q) Ei2[q] = buf_load_row4<0>(T.wsb, fwd_ie_off(G, T, 4, K2.ie[q]), 0);
-  Ei3[0] = buf_load_row4<0>(T.wsb, fwd_ie_off(G, T, 5, K3.ie[0]), 0);
-  Ei3[1] = Ei3[0]; Ei3[2] = Ei3[0];
-  const float pen0 = chain_penalties<0, -1, 0, 1>(K0, kT, kT, K0, kT, kT, Ip, P.p1, P.p2, lane);
-  const float pen1 = chain_penalties<1, -1, 1, 1>(K1, na_of(1, w), kT, K1, na_of(1, w), kT, Ip, P.p1, P.p2, lane);
-  const float pen2 = chain_penalties<2, -1, 2, 1>(K2, na_of(2, w), nb_of(2, w), K2, na_of(2, w), nb_of(2, w), Ip, P.p1, P.p2, lane);
-  const float pen3 = chain_penalties<3, -1, 3, 1>(K3, kT, kT, K3, kT, kT, Ip, P.p1, P.p2, lane);
-  Row<4> Ef[3], Ei[3], Xf[3];
-  // ---- pair 0: right / left
-  Ef[0] = C.c0; Ef[1] = C.c0; Ef[2] = C.c0;
-  Ei[0] = N.e0i; Ei[1] = N.e0i; Ei[2] = N.e0i;
-  fwd_pair_w<0, FINAL, GEN>(w, K0, Ef, Ei, Xf, 1, G, T, P.true_paths, Ct, St, pen0, X, L, [] {});
-  C.c0 = Xf[0];
-  // ---- pair 1: down / up
-  Ef[0] = sel_row(K1.carry_first, C.c1, N.e1t);
-  Ef[1] = sel_row(K1.carry_first, N.e1t, C.c1);
-  Ei[0] = N.e1i[0]; Ei[1] = N.e1i[1]; Ei[2] = N.e1i[1];
-  fwd_pair_w<1, FINAL, GEN>(w, K1, Ef, Ei, Xf, 1, G, T, P.true_paths, Ct, St, pen1, X, L, [&] {
-#ifndef STM_SKEW_X_NODRAIN
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores of the previous tile have landed
-#endif
-    lds_barrier();
-    if (publish && threadIdx.x == 0) publish_progress(publish, (unsigned)T.j);
-  });
-  {
-    const bool main_diag = !K1.restart1;
-    C.c1 = sel_row(K1.carry_first, Xf[1], Xf[0]);
-    const Row<4> bottom = sel_row(K1.carry_first && !main_diag, Xf[0], Xf[1]);
-    STM_X_STORE(buf_store_row4<kXSc1>(T.wsb, rowb_off(G, T, 0, T.i, K1.fb, true), 0, bottom));
-  }
-  // The next tile's cost rows and its first entries.
-  auto prefetch_next = [&] {
-    prefetch_cost(N.cost, G, Tn, image, L);
-    N.e0i = buf_load_row4<0>(Tn.wsb, fwd_ie_off(G, Tn, 0, K0.ie[0]), 0);
-    N.e1t = buf_load_row4<kXSc1>(Tn.wsb, have_next ? rowb_off(G, Tn, 0, Tn.i - 1, K1.ft, false) : kNowhere, 0);
-    N.e1i[0] = buf_load_row4<0>(Tn.wsb, fwd_ie_off(G, Tn, 3, K1.ie[0]), 0);
-    N.e1i[1] = buf_load_row4<0>(Tn.wsb, fwd_ie_off(G, Tn, 3, K1.ie[1]), 0);
-  };
-  if (STM_SKEW_FWD_PREFETCH_AT == 1) prefetch_next();
-  // ---- pair 2: down-right / up-left
-  Ef[0] = e2t; Ef[1] = C.c2a; Ef[2] = C.c2b;
-  fwd_pair_w<2, FINAL, GEN>(w, K2, Ef, Ei2, Xf, cls2, G, T, P.true_paths, Ct, St, pen2, X, L, [] { lds_barrier(); });
-  C.c2a = Xf[0];
-  C.c2b = Xf[1];  // (wave 3 has no third piece: unused there)
-  // (one unconditional store: a store under a condition is a branch, behind which the compiler
-  // can no longer count the accesses in flight -- DESIGN.md 4.1d)
-  STM_X_STORE(buf_store_row4<kXSc1>(T.wsb, rowb_off(G, T, 1, T.i, K2.fb, true), 0, sel_row(w < 3, Xf[2], Xf[1])));
-  if (STM_SKEW_FWD_PREFETCH_AT == 2) prefetch_next();
-  // ---- pair 3: down-left / up-right
-  Ef[0] = e3t; Ef[1] = e3t; Ef[2] = e3t;
-  fwd_pair_w<3, FINAL, GEN>(w, K3, Ef, Ei3, Xf, cls3, G, T, P.true_paths, Ct, St, pen3, X, L, [] { lds_barrier(); });
-  STM_X_STORE(buf_store_row4<kXSc1>(T.wsb, rowb_off(G, T, 2, T.i, K3.fb, true), 0, Xf[0]));
-}
-
-__device__ __forceinline__ void make_tile(TileCtx &T, const SkewGeom &G, int i, int j) {
-  T.i = i; T.j = j;
-  T.x0 = kT * j; T.y0 = kT * i;
-  T.gen = !tile_fast(G, i, j);
-}
-
-template <int FINAL>
-__global__ __launch_bounds__(4 * 64, 2) void sgm_skew_fwd_kernel(const float *__restrict__ cost_all,
-                                                                  const float *__restrict__ image_all,
-                                                                  float *__restrict__ out_all,
-                                                                  int32_t *__restrict__ disp_all,
-                                                                  float *__restrict__ ws, const SkewArgs P) {
-  __shared__ __attribute__((aligned(16))) float Ct[kT * kT * kD];
-  __shared__ __attribute__((aligned(16))) float St[kT * kT * st_stride(kD)];
-  __shared__ float Ip[kIpN];
-  __shared__ int s_unit;
-  const SkewGeom &G = P.G;
-  const int lane = threadIdx.x & 63;
-  LaneId L;
-  L.w = wave_uniform((int)(threadIdx.x >> 6));
-  L.half = lane >> 5; L.hl = lane & 31; L.d0 = L.hl * 4; L.hl16 = L.hl * 16;
-  StepCtxH2 X;
-  X.init(P.p1, L.hl, P.dlim);
-  PK K0, K1, K2, K3;
-  pk_init<0>(K0, L); pk_init<1>(K1, L); pk_init<2>(K2, L); pk_init<3>(K3, L);
-  unsigned *status = reinterpret_cast<unsigned *>(ws);
-  unsigned *prog = reinterpret_cast<unsigned *>(ws + G.prog_off);
-  const size_t npix = (size_t)G.H * G.W;
-  const int nunits = G.batch * G.nTR;
-  bool dead = false;
-  FwdCarry C;
-  FwdPre N;
-  for (;;) {
-    __syncthreads();  // (the previous unit's last readers of s_unit, Ct, St)
-    if (threadIdx.x == 0) s_unit = (int)atomicAdd(status + kTicketFwd, 1u);
-    __syncthreads();
-    const int unit = s_unit;
-    if (unit >= nunits) break;
-    const int b = unit % G.batch, i = unit / G.batch;
-    const float *image = image_all + (size_t)b * npix;
-    int32_t *disp = disp_all ? disp_all + (size_t)b * npix : nullptr;
-    TileCtx T, Tn;
-    T.cost = make_rsrc(cost_all + (size_t)b * npix * kD, (unsigned)(npix * kD * 4));
-    T.out = make_rsrc(out_all ? out_all + (size_t)b * npix * kD : ws, out_all ? (unsigned)(npix * kD * 4) : 0u);
-    T.wsb = make_rsrc(ws + img_base(G, b), (unsigned)(G.img_floats * 4));
-    Tn = T;
-    const unsigned *prog_above = prog + prog_index(G, 1, b, i > 0 ? i - 1 : 0);
-    unsigned *prog_mine = prog + prog_index(G, 1, b, i);
-    // Tile 0: everything that later tiles get from their predecessor's prefetch.
-    make_tile(T, G, i, 0);
-    unsigned seen = 0;
-    if (L.w == 0 && i > 0) wait_progress(prog_above, (unsigned)progress_needed(G, 0), seen, status, dead);
-    __syncthreads();
-    prefetch_cost(N.cost, G, T, image, L);
-    N.e0i = buf_load_row4<0>(T.wsb, fwd_ie_off(G, T, 0, K0.ie[0]), 0);
-    N.e1t = buf_load_row4<kXSc1>(T.wsb, rowb_off(G, T, 0, i - 1, K1.ft, false), 0);
-    N.e1i[0] = buf_load_row4<0>(T.wsb, fwd_ie_off(G, T, 3, K1.ie[0]), 0);
-    N.e1i[1] = buf_load_row4<0>(T.wsb, fwd_ie_off(G, T, 3, K1.ie[1]), 0);
-    C.c0 = N.e0i; C.c1 = N.e0i; C.c2a = N.e0i; C.c2b = N.e0i;  // (any defined value: tile 0's paths begin in it)
-    for (int j = 0; j < G.nTC; ++j) {
-      make_tile(T, G, i, j);
-      const bool have_next = j + 1 < G.nTC;
-      make_tile(Tn, G, i, have_next ? j + 1 : j);
-      stage_cost(N.cost, Ct, Ip, L);
-      // The band above is far enough ahead for this tile's entries and the next tile's prefetch.
-      if (L.w == 0 && i > 0) wait_progress(prog_above, (unsigned)progress_needed(G, j), seen, status, dead);
-      lds_barrier();
-      // (the band's own progress -- tiles < j are complete -- is published behind pair 1's barrier,
-      // in front of which every wave drains its stores: by then the previous tile's last stores
-      // have had a pair's time, a drain at the top of the tile would wait for them)
-      unsigned *publish = j > 0 ? prog_mine : nullptr;
-      if (T.gen) fwd_tile<FINAL, true>(P, T, Tn, have_next, K0, K1, K2, K3, C, N, image, Ct, St, Ip, X, L, lane, publish);
-      else fwd_tile<FINAL, false>(P, T, Tn, have_next, K0, K1, K2, K3, C, N, image, Ct, St, Ip, X, L, lane, publish);
-      lds_barrier();
-      if constexpr (FINAL != 0) skew_wta(St, L.w, lane, G, T.x0, T.y0, disp);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) publish_progress(prog_mine, (unsigned)G.nTC);
-  }
-}
-
-// =====================================================================================
-// Reverse pass.
-// =====================================================================================
-struct RevCarry {
-  Row<4> c0, c1, c2a, c2b;  // pair 0; pair 1 (B -> A); pair 2 (P1 -> P0, P2 -> P1)
-};
-
-// Bottom entries of a tile (the band below wrote them in this launch: sc1), requested a tile ahead.
-struct RevPre {
-  Pre cost;
-  Row<4> b1, b2, b3;
-};
-__device__ __forceinline__ void rev_bottoms(RevPre &N, const SkewGeom &G, const TileCtx &T, const PK &K1, const PK &K2,
-                                            const PK &K3) {
-  N.b1 = buf_load_row4<kXSc1>(T.wsb, rowb_off(G, T, 3, T.i + 1, K1.rb, false), 0);
-  N.b2 = buf_load_row4<kXSc1>(T.wsb, rowb_off(G, T, 4, T.i + 1, K2.rb, false), 0);
-  N.b3 = buf_load_row4<kXSc1>(T.wsb, rowb_off(G, T, 5, T.i + 1, K3.rb, false), 0);
-}
-
-template <bool GEN>
-__device__ __forceinline__ void rev_tile(const SkewArgs &P, const TileCtx &T, const TileCtx &Tn, const PK &K0,
-                                         const PK &K1, const PK &K2, const PK &K3, RevCarry &C, RevPre &N,
-                                         const float *image, const float *Ct, const float *Ip, StepCtxH2 &X,
-                                         const LaneId &L, int lane, unsigned *publish, unsigned published) {
-  const SkewGeom &G = P.G;
-  const int w = L.w;
-  const Row<4> b1 = N.b1, b2 = N.b2, b3 = N.b3;
-  const float pen01 = chain_penalties<0, 1, 1, 1>(K0, kT, kT, K1, na_of(1, w), kT, Ip, P.p1, P.p2, lane);
-  const float pen23 = chain_penalties<2, 1, 3, 1>(K2, na_of(2, w), nb_of(2, w), K3, kT, kT, Ip, P.p1, P.p2, lane);
-  Row<4> Ea[3], Eb[3], Xa[3], Xb[3];
-  // ---- pairs 0 (left) and 1 (up)
-  Ea[0] = C.c0; Ea[1] = C.c0; Ea[2] = C.c0;
-  // pair 1: the piece that enters from the right side takes the carry, the other one the bottom state
-  Eb[0] = sel_row(K1.carry_first, b1, C.c1);
-  Eb[1] = sel_row(K1.carry_first, C.c1, b1);
-  Eb[2] = b1;
-#define STM_REV01(NA) rev_pairs<0, kT, kT, 1, NA, kT, GEN>(K0, Ea, Xa, K1, Eb, Xb, G, T, Ct, pen01, X, L)
-  switch (w) {
-    case 0: STM_REV01(7); break;
-    case 1: STM_REV01(6); break;
-    case 2: STM_REV01(5); break;
-    default: STM_REV01(4); break;
-  }
-#undef STM_REV01
-  // This wave's stores of the PREVIOUS tile have landed (they have had half a tile's time; a drain
-  // at the top of the tile would wait for them), the workgroup's barrier, then the band's progress
-  // -- the tiles before this one are complete -- is published.
-#ifndef STM_SKEW_X_NODRAIN
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-  lds_barrier();
-  if (publish && threadIdx.x == 0) publish_progress(publish, published);
-  C.c0 = Xa[0];
-  STM_X_STORE(buf_store_row4<0>(T.wsb, side_off(G, T, T.j, K0.rs[0]), 0, Xa[0]));
-  {
-    // slot order [q0, q1]; the inverse chain leaves q1 at slot NA (Xb[1]) and q0 at slot 0 (Xb[0]).
-    // first half-wave: q1 = B leaves to the left (carry + side), q0 = A leaves at the top;
-    // second: q1 = A' leaves at the top, q0 = B' to the left; main diagonal: leaves at the top (Xb[0]).
-    const bool main_diag = !K1.restart1;
-    const Row<4> left = sel_row(K1.carry_first, Xb[0], Xb[1]);
-    const Row<4> top = sel_row(K1.carry_first && !main_diag, Xb[1], Xb[0]);
-    C.c1 = left;
-    const unsigned so = K1.carry_first ? K1.rs[0] : K1.rs[1];
-    STM_X_STORE(buf_store_row4<0>(T.wsb, side_off(G, T, T.j, so), 0, left));
-    STM_X_STORE(buf_store_row4<kXSc1>(T.wsb, rowb_off(G, T, 3, T.i, K1.rt, false), 0, top));
-  }
-  // The next tile's cost rows and bottom entries (half a tile ahead; held in registers no longer).
-  prefetch_cost(N.cost, G, Tn, image, L);
-  rev_bottoms(N, G, Tn, K1, K2, K3);
-  // ---- pairs 2 (up-left) and 3 (up-right)
-  Eb[0] = b3; Eb[1] = b3; Eb[2] = b3;
-  if (w < 3) {
-    Ea[0] = C.c2a; Ea[1] = C.c2b; Ea[2] = b2;
-  } else {
-    Ea[0] = C.c2a; Ea[1] = b2; Ea[2] = b2;
-  }
-#define STM_REV23(NA, NB) rev_pairs<2, NA, NB, 3, kT, kT, GEN>(K2, Ea, Xa, K3, Eb, Xb, G, T, Ct, pen23, X, L)
-  switch (w) {
-    case 0: STM_REV23(1, 5); break;
-    case 1: STM_REV23(2, 6); break;
-    case 2: STM_REV23(3, 7); break;
-    default: STM_REV23(4, kT); break;
-  }
-#undef STM_REV23
-  // pair 2: P0 leaves at the top; P1 to the left (-> the next tile's P0), P2 to the left (-> its P1)
-  STM_X_STORE(buf_store_row4<kXSc1>(T.wsb, rowb_off(G, T, 4, T.i, K2.rt, false), 0, Xa[0]));
-  C.c2a = Xa[1];
-  STM_X_STORE(buf_store_row4<0>(T.wsb, side_off(G, T, T.j, K2.rs[1]), 0, Xa[1]));
-  C.c2b = sel_row(w < 3, Xa[2], Xa[1]);
-  STM_X_STORE(buf_store_row4<0>(T.wsb, side_off(G, T, T.j, K2.rs[2]), 0, C.c2b));  // (wave 3: no third piece, offset kNowhere)
-  STM_X_STORE(buf_store_row4<kXSc1>(T.wsb, rowb_off(G, T, 5, T.i, K3.rt, false), 0, Xb[0]));
-}
-
-__global__ __launch_bounds__(4 * 64, STM_SKEW_REV_OCC) void sgm_skew_rev_kernel(const float *__restrict__ cost_all,
-                                                                  const float *__restrict__ image_all,
-                                                                  float *__restrict__ ws, const SkewArgs P) {
-  __shared__ __attribute__((aligned(16))) float Ct[kT * kT * kD];
-  __shared__ float Ip[kIpN];
-  __shared__ int s_unit;
-  const SkewGeom &G = P.G;
-  const int lane = threadIdx.x & 63;
-  LaneId L;
-  L.w = wave_uniform((int)(threadIdx.x >> 6));
-  L.half = lane >> 5; L.hl = lane & 31; L.d0 = L.hl * 4; L.hl16 = L.hl * 16;
-  StepCtxH2 X;
-  X.init(P.p1, L.hl, P.dlim);
-  PK K0, K1, K2, K3;
-  pk_init<0>(K0, L); pk_init<1>(K1, L); pk_init<2>(K2, L); pk_init<3>(K3, L);
-  unsigned *status = reinterpret_cast<unsigned *>(ws);
-  unsigned *prog = reinterpret_cast<unsigned *>(ws + G.prog_off);
-  const size_t npix = (size_t)G.H * G.W;
-  const int nunits = G.batch * G.nTR;
-  bool dead = false;
-  RevCarry C;
-  RevPre N;
-  for (;;) {
-    __syncthreads();
-    if (threadIdx.x == 0) s_unit = (int)atomicAdd(status + kTicketRev, 1u);
-    __syncthreads();
-    const int unit = s_unit;
-    if (unit >= nunits) break;
-    const int b = unit % G.batch, i = G.nTR - 1 - unit / G.batch;
-    const float *image = image_all + (size_t)b * npix;
-    TileCtx T, Tn;
-    T.cost = make_rsrc(cost_all + (size_t)b * npix * kD, (unsigned)(npix * kD * 4));
-    T.out = T.cost;
-    T.wsb = make_rsrc(ws + img_base(G, b), (unsigned)(G.img_floats * 4));
-    Tn = T;
-    const bool below = i + 1 < G.nTR;
-    const unsigned *prog_below = prog + prog_index(G, 0, b, below ? i + 1 : i);
-    unsigned *prog_mine = prog + prog_index(G, 0, b, i);
-    make_tile(T, G, i, G.nTC - 1);
-    unsigned seen = 0;
-    if (L.w == 0 && below) wait_progress(prog_below, (unsigned)progress_needed(G, 0), seen, status, dead);
-    __syncthreads();
-    prefetch_cost(N.cost, G, T, image, L);
-    rev_bottoms(N, G, T, K1, K2, K3);
-    Row<4> zero;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) zero.v[k] = 0.0f;
-    C.c0 = zero; C.c1 = zero; C.c2a = zero; C.c2b = zero;  // (the last tile's paths begin in it)
-    for (int jj = 0; jj < G.nTC; ++jj) {
-      const int j = G.nTC - 1 - jj;
-      make_tile(T, G, i, j);
-      make_tile(Tn, G, i, j > 0 ? j - 1 : 0);
-      stage_cost(N.cost, Ct, Ip, L);
-      // The band below is far enough ahead for the next tile's prefetch.
-      if (L.w == 0 && below) wait_progress(prog_below, (unsigned)progress_needed(G, jj), seen, status, dead);
-      lds_barrier();
-      unsigned *publish = jj > 0 ? prog_mine : nullptr;
-      if (T.gen) rev_tile<true>(P, T, Tn, K0, K1, K2, K3, C, N, image, Ct, Ip, X, L, lane, publish, (unsigned)jj);
-      else rev_tile<false>(P, T, Tn, K0, K1, K2, K3, C, N, image, Ct, Ip, X, L, lane, publish, (unsigned)jj);
-      lds_barrier();  // (the next tile's staging overwrites the cost tile)
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) publish_progress(prog_mine, (unsigned)G.nTC);
-  }
-}
-
-}  // namespace
 
 bool skew_covers(int H, int W, int D, int batch, int flags) {
   if (flags & (STM_SGM_SINGLE_PASSES | STM_SGM_EXACT_NONFINITE | STM_SGM_ACCUMULATE)) return false;
-  if (D != 128) return false;
+  if (D != 128 && D != 256) return false;
   if (H < 1 || W < 1 || batch < 1 || batch > 65535) return false;
   skew::SkewGeom G;
   long long total = 0, zero = 0;
@@ -941,35 +53,22 @@ size_t skew_workspace_bytes(int H, int W, int D, int batch) {
 int skew_run(const float *cost, const float *left, float *out, int32_t *disp, int H, int W, int D,
              float penalty1, float penalty2, int flags, void *workspace, size_t workspace_bytes, int batch,
              hipStream_t stream, int final_mode, int cus) {
-  SkewArgs A;
+  skew::SkewGeom G;
   long long total = 0, zero = 0;
-  skew::make_geom(H, W, D, batch, A.G, total, zero);
+  skew::make_geom(H, W, D, batch, G, total, zero);
   const size_t need = (size_t)total * sizeof(float);
   STM_REQUIRE(workspace && workspace_bytes >= need, STM_EWORKSPACE,
               "stm_sgm_f32: needs a workspace of %zu bytes (stm_sgm_workspace_bytes)", need);
-  A.p1 = penalty1; A.p2 = penalty2;
-  A.dlim = (flags & STM_SGM_FULL_MIN) ? D : D - 1;
-  A.true_paths = (flags & STM_SGM_TRUE_PATHS) ? 1 : 0;
   float *ws = static_cast<float *>(workspace);
+  // status word, unit tickets, progress counters
   if (hipMemsetAsync(ws, 0, (size_t)zero * sizeof(float), stream) != hipSuccess)
     return fail(STM_EHIP, "stm_sgm_f32 (skewed tiles): hipMemsetAsync failed");
-  const long long units = (long long)batch * A.G.nTR;
-  {
-    const long long wgs = (long long)cus * STM_SKEW_REV_OCC;
-    const dim3 grid((unsigned)(units < wgs ? units : wgs)), block(4 * 64);
-    hipLaunchKernelGGL(sgm_skew_rev_kernel, grid, block, 0, stream, cost, left, ws, A);
-    const int rc = check_launch("stm_sgm_f32 (skewed tiles: reverse pass)");
-    if (rc != STM_OK) return rc;
-  }
-  const long long wgs = (long long)cus * 2;
-  const dim3 grid((unsigned)(units < wgs ? units : wgs)), block(4 * 64);
-  if (final_mode == 0)
-    hipLaunchKernelGGL((sgm_skew_fwd_kernel<0>), grid, block, 0, stream, cost, left, out, disp, ws, A);
-  else if (final_mode == 1)
-    hipLaunchKernelGGL((sgm_skew_fwd_kernel<1>), grid, block, 0, stream, cost, left, out, disp, ws, A);
-  else
-    hipLaunchKernelGGL((sgm_skew_fwd_kernel<2>), grid, block, 0, stream, cost, left, out, disp, ws, A);
-  return check_launch("stm_sgm_f32 (skewed tiles: forward pass)");
+  const int dlim = (flags & STM_SGM_FULL_MIN) ? D : D - 1;
+  const int true_paths = (flags & STM_SGM_TRUE_PATHS) ? 1 : 0;
+  return D == 128 ? skew_launch_d128(cost, left, out, disp, ws, G, penalty1, penalty2, dlim, true_paths, stream,
+                                     final_mode, cus)
+                  : skew_launch_d256(cost, left, out, disp, ws, G, penalty1, penalty2, dlim, true_paths, stream,
+                                     final_mode, cus);
 }
 
 }  // namespace stm

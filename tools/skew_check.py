@@ -10,9 +10,9 @@ import stereomatch
 dev = torch.device("cuda:0")
 shapes = [(8, 8, 1), (16, 16, 1), (24, 40, 1), (40, 24, 1), (40, 90, 2), (90, 40, 2), (33, 129, 1), (1, 9, 1), (9, 1, 1),
           (13, 30, 3), (95, 151, 2), (120, 200, 4), (375, 450, 2)]
+D = int(os.environ.get("D", "128"))
 if len(sys.argv) > 1:
     shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
-D = 128
 bad = 0
 for H, W, B in shapes:
     rng = np.random.default_rng(H * 1000 + W)
