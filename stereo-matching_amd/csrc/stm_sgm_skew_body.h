@@ -17,6 +17,9 @@ using std::integral_constant;
 #ifndef STM_SKEW_FWD_PREFETCH_AT
 #define STM_SKEW_FWD_PREFETCH_AT 2  // the next tile's cost rows are requested behind pair 1 / pair 2
 #endif
+#ifndef STM_SKEW_POLL_SLEEP
+#define STM_SKEW_POLL_SLEEP 16  // s_sleep between two polls of a progress counter (units of 64 clocks)
+#endif
 #ifndef STM_SKEW_REV_OCC
 #define STM_SKEW_REV_OCC 2  // workgroups of the reverse pass per CU (registers: 512 / (4 x this) per lane)
 #endif
@@ -39,6 +42,11 @@ constexpr int kSumPixBytes = st_stride(kD) * 4;
 constexpr int kIpW = kT + 4;                 // intensity patch: u in [-2, 9], r in [-1, 8]
 constexpr int kIpN = kIpW * (kT + 2);
 
+#ifdef STM_SKEW_X_STATS
+__device__ unsigned long long g_skew_pub[256];   // band 0 of the forward pass: when value k was published
+__device__ unsigned long long g_skew_see[512];   // band 1: [2 k] when tile k started, [2 k + 1] the counter value it had seen by then
+__device__ unsigned long long g_skew_stamps[8192];  // [band][8]: forward pass, image 0: start of tiles 0, 1, 2, 4, 8, 32, 128, last
+#endif
 struct SkewArgs {
   SkewGeom G;
   float p1, p2;
@@ -281,19 +289,35 @@ __device__ __forceinline__ float chain_penalties(const PK &KA, int naA, int nbA,
   return sgm_penalty(Ip[(r + 1) * kIpW + u + 2], Ip[(r + dr + 1) * kIpW + u + du + 2], p1, p2);
 }
 
-// Per-slot flags of a gen tile.
-struct SlotFlags {
-  bool valid, begin_f, begin_i;
-};
-template <int PHASE>
-__device__ __forceinline__ SlotFlags slot_flags(const SkewGeom &G, const TileCtx &T, int pix) {
-  const int u = pix & (kT - 1), r = pix >> 3;
-  const int x = T.x0 + u - r, y = T.y0 + r;
-  SlotFlags f;
-  f.valid = in_image(G, x, y);
-  f.begin_f = f.valid && !in_image(G, x - img_dx(PHASE), y - img_dy(PHASE));
-  f.begin_i = f.valid && !in_image(G, x + img_dx(PHASE), y + img_dy(PHASE));
-  return f;
+// Gen tiles: where the lane's chain BEGINS a path (L = C): bit s of `bf` / `bi`: slot s lies in the
+// image and its forward predecessor / successor does not.  Inside a piece the neighbour is the
+// neighbouring slot; at a piece's ends it lies in another tile.
+__device__ __forceinline__ bool in_image_u(const SkewGeom &G, int x, int y) {
+  return (unsigned)x < (unsigned)G.W && (unsigned)y < (unsigned)G.H;
+}
+template <int PHASE, int NA, int NB>
+__device__ __forceinline__ void begin_masks(const PK &K, const SkewGeom &G, const TileCtx &T, unsigned &bf, unsigned &bi) {
+  constexpr int NP = NB < kT ? 3 : (NA < kT ? 2 : 1);
+  constexpr int dx = img_dx(PHASE), dy = img_dy(PHASE);
+  unsigned v = 0, pv = 0, sv = 0;
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    const int st = q == 0 ? 0 : (q == 1 ? NA : NB), en = q == 0 ? NA : (q == 1 ? NB : kT);
+    const int u = K.pix[q] & (kT - 1), r = K.pix[q] >> 3;
+    const int x = T.x0 + u - r, y = T.y0 + r;  // the piece's first pixel
+#pragma unroll
+    for (int t = 0; t < kT; ++t) {
+      if (st + t < en) v |= in_image_u(G, x + t * dx, y + t * dy) ? (1u << (st + t)) : 0u;
+    }
+    pv |= in_image_u(G, x - dx, y - dy) ? (1u << st) : 0u;
+    sv |= in_image_u(G, x + (en - st) * dx, y + (en - st) * dy) ? (1u << (en - 1)) : 0u;
+  }
+  constexpr unsigned starts = 1u | (NA < kT ? 1u << NA : 0u) | (NB < kT ? 1u << NB : 0u);
+  constexpr unsigned ends = (1u << (NA - 1)) | (NA < kT ? 1u << (NB - 1) : 0u) | (1u << (kT - 1));
+  pv |= (v << 1) & ~starts;
+  sv |= (v >> 1) & ~ends;
+  bf = v & ~pv;
+  bi = v & ~sv;
 }
 __device__ __forceinline__ Row<4> sel_row(bool c, const Row<4> &a, const Row<4> &b) {
   Row<4> r;
@@ -307,7 +331,7 @@ __device__ __forceinline__ Row<4> sel_row(bool c, const Row<4> &a, const Row<4> 
 // together (slot s of the forward chain with slot 7 - s of the inverse chain), the update
 // S = ((S + [I x pre]) + F) + I x inv of the sum tile from the fifth step on (stm_sgm_tile_h2.hip).
 //   Ef / Ei   entry states per piece (slot order); Xf: the forward chain's state after each piece.
-//   cls       count class of the tile for this pair (skew::count_class); gen tiles pass 3.
+//   cls       count class of the tile for this pair (skew::count_class).
 // =====================================================================================
 template <int PHASE, int NA, int NB, int FINAL, bool GEN, typename Between>
 __device__ __forceinline__ void fwd_pair(const PK &K, const Row<4> (&Ef)[3], const Row<4> (&Ei)[3], Row<4> (&Xf)[3],
@@ -341,6 +365,8 @@ __device__ __forceinline__ void fwd_pair(const PK &K, const Row<4> (&Ef)[3], con
   Row<4> LF[kT], LI[kT];
   Row<4> pf = Ef[0];
   Row<4> pi = Ei[NP - 1];
+  unsigned bf = 0, bi = 0;
+  if constexpr (GEN) begin_masks<PHASE, NA, NB>(K, G, T, bf, bi);
   auto update = [&](auto s_, Row<4> &acc) {
     constexpr int s = decltype(s_)::value;
     constexpr int q = s < NA ? 0 : (s < NB ? 1 : 2);
@@ -423,9 +449,8 @@ __device__ __forceinline__ void fwd_pair(const PK &K, const Row<4> (&Ef)[3], con
       }
       step2<s, 8 + r>(pf, cf, pi, ci, pen, X, XI);
       if constexpr (GEN) {
-        const SlotFlags ff = slot_flags<PHASE>(G, T, pix_of(s_)), fi = slot_flags<PHASE>(G, T, pix_of(integral_constant<int, r>()));
-        pf = sel_row(ff.begin_f, cf, pf);
-        pi = sel_row(fi.begin_i, ci, pi);
+        pf = sel_row(((bf >> s) & 1u) != 0u, cf, pf);
+        pi = sel_row(((bi >> r) & 1u) != 0u, ci, pi);
       }
       LF[s] = pf;
       LI[r] = pi;
@@ -457,6 +482,7 @@ __device__ __forceinline__ void fwd_pair(const PK &K, const Row<4> (&Ef)[3], con
       if constexpr (NB < kT && s == NB) pf = Ef[2];
       const Row<4> c = h2_lds_row(Ct, addr(s_));
       pf = step1<s>(pf, c, pen, X);
+      if constexpr (GEN) pf = sel_row(((bf >> s) & 1u) != 0u, c, pf);
       LF[s] = pf;
       LI[s] = pf;  // (not added: inv == 0)
       note_exit(s_);
@@ -541,6 +567,11 @@ __device__ __forceinline__ void rev_pairs(const PK &KA, const Row<4> (&Ea)[3], R
     constexpr int q = s < NAB ? 0 : (s < NBB ? 1 : 2), st = q == 0 ? 0 : (q == 1 ? NAB : NBB);
     return KB.pix[q] + (s - st) * tile_pstep(PB);
   };
+  unsigned bia = 0, bib = 0, unused_f;
+  if constexpr (GEN) {
+    begin_masks<PA, NAA, NBA>(KA, G, T, unused_f, bia);
+    begin_masks<PB, NAB, NBB>(KB, G, T, unused_f, bib);
+  }
   Row<4> pa = Ea[NPA - 1], pb = Eb[NPB - 1];
   Row<4> ca = h2_lds_row(Ct, pix_a(integral_constant<int, kT - 1>()) * kRowBytes + hl16);
   Row<4> cb = h2_lds_row(Ct, pix_b(integral_constant<int, kT - 1>()) * kRowBytes + hl16);
@@ -557,9 +588,8 @@ __device__ __forceinline__ void rev_pairs(const PK &KA, const Row<4> (&Ea)[3], R
     }
     step2<r, 8 + r>(pa, ca, pb, cb, pen, X, XB);
     if constexpr (GEN) {
-      const SlotFlags fa = slot_flags<PA>(G, T, pix_a(r_)), fb = slot_flags<PB>(G, T, pix_b(r_));
-      pa = sel_row(fa.begin_i, ca, pa);
-      pb = sel_row(fb.begin_i, cb, pb);
+      pa = sel_row(((bia >> r) & 1u) != 0u, ca, pa);
+      pb = sel_row(((bib >> r) & 1u) != 0u, cb, pb);
     }
     // (pieces a chain does not have get a defined value too)
     if constexpr (r == 0) Xa[0] = pa;
@@ -580,6 +610,15 @@ __device__ __forceinline__ void rev_pairs(const PK &KA, const Row<4> (&Ea)[3], R
 // ---- progress counters --------------------------------------------------------------------------
 // Waits (one wave) until *p >= need.  Bounded like the sweeps' waits: ~2 s, then the status word is
 // set and nobody waits again.
+__device__ __forceinline__ unsigned poll_counter(const unsigned *p) {
+#ifdef STM_SKEW_X_POLL_RMW
+  unsigned v = 0;
+  if ((threadIdx.x & 63) == 0) v = __hip_atomic_fetch_add(const_cast<unsigned *>(p), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+#else
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
 // `seen`: the counter's value when this wave last looked (it only grows): no load at all while
 // that already suffices -- a band's owner that runs well behind its neighbour polls once per
 // several tiles.
@@ -589,13 +628,22 @@ __device__ __forceinline__ void wait_progress(const unsigned *p, unsigned need, 
   return;
 #endif
   if (dead || seen >= need) return;
-  seen = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  seen = poll_counter(p);
   if (seen >= need) return;
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-  for (;;) {
-    __builtin_amdgcn_s_sleep(8);
-    seen = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (unsigned trip = 1;; ++trip) {
+    __builtin_amdgcn_s_sleep(STM_SKEW_POLL_SLEEP);
+    seen = poll_counter(p);
+#ifdef STM_SKEW_X_STATS  // header words 8..: waits that looped, polls, 10-ns ticks waited
+    if ((threadIdx.x & 63) == 0) atomicAdd(status + 9, 1u);
+    if (seen >= need && (threadIdx.x & 63) == 0) {
+      atomicAdd(status + 8, 1u);
+      atomicAdd(status + 10, (unsigned)(__builtin_amdgcn_s_memrealtime() - t0));
+    }
+#endif
     if (seen >= need) return;
+    // (the status word is ONE line for the whole chip: looked at every 256th trip only)
+    if ((trip & 255u) != 0u) continue;
     if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { dead = true; return; }
     if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
       dead = true;
@@ -661,11 +709,11 @@ template <int FINAL, bool GEN>
 __device__ __forceinline__ void fwd_tile(const SkewArgs &P, const TileCtx &T, const TileCtx &Tn, bool have_next,
                                          const PK &K0, const PK &K1, const PK &K2, const PK &K3, FwdCarry &C,
                                          FwdPre &N, const float *image, float *Ct, float *St, const float *Ip,
-                                         Ctx &X, const LaneId &L, int lane, unsigned *publish) {
+                                         Ctx &X, const LaneId &L, int lane, unsigned *publish, unsigned *stats) {
   const SkewGeom &G = P.G;
   const int w = L.w;
-  const int cls2 = GEN ? 3 : count_class(2, G, T.i, T.j, P.true_paths);
-  const int cls3 = GEN ? 3 : count_class(3, G, T.i, T.j, P.true_paths);
+  const int cls2 = count_class(2, G, T.i, T.j, P.true_paths);
+  const int cls3 = count_class(3, G, T.i, T.j, P.true_paths);
   // Entries of pairs 2 and 3 (a global load takes longer than a pair: pairs 0 and 1 cover them).
   const Row<4> e2t = buf_load_row4<kXSc1>(T.wsb, rowb_off(G, T, 1, T.i - 1, K2.ft, false), 0);
   const Row<4> e3t = buf_load_row4<kXSc1>(T.wsb, rowb_off(G, T, 2, T.i - 1, K3.ft, false), 0);
@@ -689,11 +737,26 @@ __device__ __forceinline__ void fwd_tile(const SkewArgs &P, const TileCtx &T, co
   Ef[1] = sel_row(K1.carry_first, N.e1t, C.c1);
   Ei[0] = N.e1i[0]; Ei[1] = N.e1i[1]; Ei[2] = N.e1i[1];
   fwd_pair_w<1, FINAL, GEN>(w, K1, Ef, Ei, Xf, 1, G, T, P.true_paths, Ct, St, pen1, X, L, [&] {
+#ifdef STM_SKEW_X_STATS
+    const unsigned long long td0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifndef STM_SKEW_X_NODRAIN
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores of the previous tile have landed
 #endif
+#ifdef STM_SKEW_X_STATS
+    const unsigned long long td1 = __builtin_amdgcn_s_memrealtime();
+#endif
     lds_barrier();
+#ifdef STM_SKEW_X_STATS
+    if (threadIdx.x == 0) {
+      atomicAdd(stats + 11, (unsigned)(td1 - td0));
+      atomicAdd(stats + 12, (unsigned)(__builtin_amdgcn_s_memrealtime() - td1));
+    }
+#endif
     if (publish && threadIdx.x == 0) publish_progress(publish, (unsigned)T.j);
+#ifdef STM_SKEW_X_STATS
+    if (threadIdx.x == 0 && T.i == 0 && T.j < 256) g_skew_pub[T.j] = __builtin_amdgcn_s_memrealtime();
+#endif
   });
   {
     const bool main_diag = !K1.restart1;
@@ -729,6 +792,9 @@ __device__ __forceinline__ void make_tile(TileCtx &T, const SkewGeom &G, int i, 
   T.i = i; T.j = j;
   T.x0 = kT * j; T.y0 = kT * i;
   T.gen = !tile_fast(G, i, j);
+#ifdef STM_SKEW_X_NOGEN  // (timing experiment: every tile takes the fast form; results are wrong)
+  T.gen = false;
+#endif
 }
 
 template <int FINAL>
@@ -774,7 +840,7 @@ __global__ __launch_bounds__(kThreads, kD == 128 ? 2 : 1) void sgm_skew_fwd_kern
     unsigned *prog_mine = prog + prog_index(G, 1, b, i);
     // Tile 0: everything that later tiles get from their predecessor's prefetch.
     make_tile(T, G, i, 0);
-    unsigned seen = 0;
+    unsigned seen = 0, ahead = 0;
     if (L.w == 0 && i > 0) wait_progress(prog_above, (unsigned)progress_needed(G, 0), seen, status, dead);
     __syncthreads();
     prefetch_cost(N.cost, G, T, image, L);
@@ -787,16 +853,50 @@ __global__ __launch_bounds__(kThreads, kD == 128 ? 2 : 1) void sgm_skew_fwd_kern
       make_tile(T, G, i, j);
       const bool have_next = j + 1 < G.nTC;
       make_tile(Tn, G, i, have_next ? j + 1 : j);
+#ifdef STM_SKEW_X_STATS
+      const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
+      if (threadIdx.x == 0 && b == 0 && i < 1024) {
+        const int k = j == 0 ? 0 : (j == 1 ? 1 : (j == 2 ? 2 : (j == 4 ? 3 : (j == 8 ? 4 : (j == 32 ? 5 : (j == 128 ? 6 : (j == G.nTC - 1 ? 7 : -1)))))));
+        if (k >= 0) g_skew_stamps[i * 8 + k] = ts0;
+      }
+#endif
       stage_cost(N.cost, Ct, Ip, L);
+#ifdef STM_SKEW_X_STATS
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      const unsigned long long ts1 = __builtin_amdgcn_s_memrealtime();
+#endif
       // The band above is far enough ahead for this tile's entries and the next tile's prefetch.
-      if (L.w == 0 && i > 0) wait_progress(prog_above, (unsigned)progress_needed(G, j), seen, status, dead);
+      // `ahead`: the counter as requested a tile ago -- a band that follows its neighbour closely
+      // needs a new value every tile, and a poll at this point is a memory round trip on the
+      // band's critical path: its tiles then take that much longer than its neighbour's, it falls
+      // behind until the polls become rare, and so does every band behind it, each by a little
+      // more (a single 1080p image: 40 ms instead of 13).  Requested early, the value is here.
+      if (L.w == 0 && i > 0) {
+        seen = ahead > seen ? ahead : seen;
+        wait_progress(prog_above, (unsigned)progress_needed(G, j), seen, status, dead);
+      }
+#ifdef STM_SKEW_X_STATS
+      const unsigned long long ts2 = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef STM_SKEW_X_STATS
+      if (threadIdx.x == 0 && i == 1 && j < 256) { g_skew_see[2 * j] = __builtin_amdgcn_s_memrealtime(); g_skew_see[2 * j + 1] = seen; }
+#endif
       lds_barrier();
+      if (L.w == 0 && i > 0) ahead = poll_counter(prog_above);  // (looked at at the top of the next tile)
+#ifdef STM_SKEW_X_STATS
+      if (threadIdx.x == 0 && j > 0) {
+        atomicAdd(status + 13, (unsigned)(ts1 - ts0));
+        atomicAdd(status + 14, (unsigned)(ts2 - ts1));
+        atomicAdd(status + 15, (unsigned)(__builtin_amdgcn_s_memrealtime() - ts2));
+        atomicAdd(status + 16, 1u);
+      }
+#endif
       // (the band's own progress -- tiles < j are complete -- is published behind pair 1's barrier,
       // in front of which every wave drains its stores: by then the previous tile's last stores
       // have had a pair's time, a drain at the top of the tile would wait for them)
       unsigned *publish = j > 0 ? prog_mine : nullptr;
-      if (T.gen) fwd_tile<FINAL, true>(P, T, Tn, have_next, K0, K1, K2, K3, C, N, image, Ct, St, Ip, X, L, lane, publish);
-      else fwd_tile<FINAL, false>(P, T, Tn, have_next, K0, K1, K2, K3, C, N, image, Ct, St, Ip, X, L, lane, publish);
+      if (T.gen) fwd_tile<FINAL, true>(P, T, Tn, have_next, K0, K1, K2, K3, C, N, image, Ct, St, Ip, X, L, lane, publish, status);
+      else fwd_tile<FINAL, false>(P, T, Tn, have_next, K0, K1, K2, K3, C, N, image, Ct, St, Ip, X, L, lane, publish, status);
       lds_barrier();
       if constexpr (FINAL != 0) skew_wta(St, L.w, lane, G, T.x0, T.y0, disp);
     }
@@ -947,7 +1047,7 @@ __global__ __launch_bounds__(kThreads, kD == 128 ? STM_SKEW_REV_OCC : 1) void sg
     const unsigned *prog_below = prog + prog_index(G, 0, b, below ? i + 1 : i);
     unsigned *prog_mine = prog + prog_index(G, 0, b, i);
     make_tile(T, G, i, G.nTC - 1);
-    unsigned seen = 0;
+    unsigned seen = 0, ahead = 0;
     if (L.w == 0 && below) wait_progress(prog_below, (unsigned)progress_needed(G, 0), seen, status, dead);
     __syncthreads();
     prefetch_cost(N.cost, G, T, image, L);
@@ -961,9 +1061,13 @@ __global__ __launch_bounds__(kThreads, kD == 128 ? STM_SKEW_REV_OCC : 1) void sg
       make_tile(T, G, i, j);
       make_tile(Tn, G, i, j > 0 ? j - 1 : 0);
       stage_cost(N.cost, Ct, Ip, L);
-      // The band below is far enough ahead for the next tile's prefetch.
-      if (L.w == 0 && below) wait_progress(prog_below, (unsigned)progress_needed(G, jj), seen, status, dead);
+      // The band below is far enough ahead for the next tile's prefetch (`ahead`: see the forward pass).
+      if (L.w == 0 && below) {
+        seen = ahead > seen ? ahead : seen;
+        wait_progress(prog_below, (unsigned)progress_needed(G, jj), seen, status, dead);
+      }
       lds_barrier();
+      if (L.w == 0 && below) ahead = poll_counter(prog_below);
       unsigned *publish = jj > 0 ? prog_mine : nullptr;
       if (T.gen) rev_tile<true>(P, T, Tn, K0, K1, K2, K3, C, N, image, Ct, Ip, X, L, lane, publish, (unsigned)jj);
       else rev_tile<false>(P, T, Tn, K0, K1, K2, K3, C, N, image, Ct, Ip, X, L, lane, publish, (unsigned)jj);
@@ -1007,3 +1111,15 @@ int skew_launch_d256
 }
 
 }  // namespace stm
+
+#ifdef STM_SKEW_X_STATS
+#if STM_SKEW_D == 128
+extern "C" int stm_debug_skew_stamps_d128(unsigned long long *dst) {
+#else
+extern "C" int stm_debug_skew_stamps_d256(unsigned long long *dst) {
+#endif
+  hipMemcpyFromSymbol(dst + 8192, HIP_SYMBOL(stm::g_skew_pub), sizeof(unsigned long long) * 256);
+  hipMemcpyFromSymbol(dst + 8192 + 256, HIP_SYMBOL(stm::g_skew_see), sizeof(unsigned long long) * 512);
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(stm::g_skew_stamps), sizeof(unsigned long long) * 8192);
+}
+#endif

@@ -41,6 +41,10 @@ using tiled::kT;                 // tile side (8)
 constexpr int kSide = 29;          // states a tile hands to its left / right neighbour (side block)
 constexpr int kHeaderFloats = 64;  // 256 bytes: status word, two unit tickets, padding
 constexpr int kTicketRev = 1, kTicketFwd = 2;  // 32-bit words of the header
+// A progress counter has a 128-byte line to itself: a band's owner polls its neighbour's counter
+// while it waits, and with the counters of 32 bands in one line every publishing store queued up
+// behind the polls of up to 32 waiting workgroups (a single 1080p image: 40 ms instead of 13).
+constexpr int kProgStride = 32;  // 32-bit words between two counters
 
 // Pairs in the reference's order: 0 right / left, 1 down / up, 2 down-right / up-left,
 // 3 down-left / up-right.  Step of a pair's FORWARD direction in the image and in a tile.
@@ -55,7 +59,7 @@ struct SkewGeom {
   int H, W, D;
   int nTR, nTC;         // bands of 8 rows; skewed tile columns: u = x + r covers [0, W + 7)
   int batch;
-  long long prog_off;   // [2 passes][batch][nTR] 32-bit progress counters (tiles finished in a band)
+  long long prog_off;   // [2 passes][batch][nTR] progress counters (tiles finished in a band), one per 128-byte line
   long long img_off;    // per image: [6][nTR][W][D] row border states, then [nTR][nTC][kSide][D] side blocks
   long long img_floats;
   long long side_in_img;  // offset of the side blocks inside an image's block
@@ -72,7 +76,7 @@ STM_HD bool make_geom(int H, int W, int D, int batch, SkewGeom &G, long long &to
   G.batch = batch;
   long long off = kHeaderFloats;
   G.prog_off = off;
-  off += (2ll * batch * G.nTR + 3) / 4 * 4;  // (keeps what follows 16-byte aligned)
+  off += 2ll * batch * G.nTR * kProgStride;
   zero_floats = off;
   G.img_off = off;
   G.side_in_img = 6ll * G.nTR * W * D;
@@ -114,7 +118,7 @@ STM_HD long long side_in_img(const SkewGeom &G, int t, int j, int idx) {
 }
 STM_HD long long img_base(const SkewGeom &G, int b) { return G.img_off + (long long)b * G.img_floats; }
 STM_HD long long prog_index(const SkewGeom &G, int pass, int b, int t) {
-  return ((long long)pass * G.batch + b) * G.nTR + t;
+  return (((long long)pass * G.batch + b) * G.nTR + t) * kProgStride;
 }
 
 // ---- chains ---------------------------------------------------------------------------------------
@@ -208,7 +212,10 @@ STM_HD int count_class(int phase, const SkewGeom &G, int i, int j, int true_path
 // finished tiles from the band's first one in processing order): enough for tile j's own entries
 // and for prefetching those of the next tile.
 STM_HD int progress_needed(const SkewGeom &G, int jj /* tile's number in processing order */) {
-  return imin_(jj + 3, G.nTC);
+#ifndef STM_SKEW_LEAD
+#define STM_SKEW_LEAD 3
+#endif
+  return imin_(jj + STM_SKEW_LEAD, G.nTC);
 }
 
 }  // namespace skew

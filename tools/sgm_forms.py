@@ -27,7 +27,7 @@ def main():
     C = stereomatch.cost.SSD(D)(L, R)
     res = {}
     forms = os.environ.get("FORMS", "paired,tiled,walks,skew").split(",")
-    forms = [f for f in forms if f != "skew" or D == 128]
+    forms = [f for f in forms if f != "skew" or D in (128, 256)]
     for form in forms:
         sgm = stereomatch.aggregation.Semiglobal(form=form)
         for fused in (True, False):
