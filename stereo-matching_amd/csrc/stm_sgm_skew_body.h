@@ -335,7 +335,7 @@ __device__ __forceinline__ Row<4> sel_row(bool c, const Row<4> &a, const Row<4> 
 // =====================================================================================
 template <int PHASE, int NA, int NB, int FINAL, bool GEN, typename Between>
 __device__ __forceinline__ void fwd_pair(const PK &K, const Row<4> (&Ef)[3], const Row<4> (&Ei)[3], Row<4> (&Xf)[3],
-                                         int cls, const SkewGeom &G, const TileCtx &T, int true_paths,
+                                         int cls, bool sp, const SkewGeom &G, const TileCtx &T, int true_paths,
                                          const float *Ct, float *St, float pen, Ctx &X, const LaneId &L,
                                          Between between) {
   constexpr int pstep = tile_pstep(PHASE);
@@ -343,7 +343,6 @@ __device__ __forceinline__ void fwd_pair(const PK &K, const Row<4> (&Ef)[3], con
   Ctx XI = X;
   const int hl16 = L.hl16;
   const bool run_inv = cls != 0;
-  const bool counted = PHASE >= 2 && cls == 3;
   auto pix_of = [&](auto s_) {
     constexpr int s = decltype(s_)::value;
     constexpr int q = s < NA ? 0 : (s < NB ? 1 : 2), st = q == 0 ? 0 : (q == 1 ? NA : NB);
@@ -351,15 +350,16 @@ __device__ __forceinline__ void fwd_pair(const PK &K, const Row<4> (&Ef)[3], con
   };
   auto addr = [&](auto s_) { return pix_of(s_) * kRowBytes + hl16; };
   auto saddr = [&](auto s_) { return pix_of(s_) * kSumPixBytes + hl16; };
-  // Counts of the lane's pieces (cls >= 2): per piece, from its first pixel's image coordinates.
-  int pre[3] = {0, 0, 0}, inv[3] = {1, 1, 1};
+  // Whether the inverse pass of the lane's pieces counts at all (cls >= 2), from each piece's first
+  // pixel.  A line that counts several times, or before its forward pass, is a DEFERRED line
+  // (stm_sgm_skew_index.h): its pixels get the plain update here -- a value nobody uses -- and
+  // their real sum from finish_deferred.
+  int inv[3] = {1, 1, 1};
   if (PHASE >= 2 && cls >= 2) {
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
       const int u = K.pix[q] & (kT - 1), r = K.pix[q] >> 3;
-      const tiled::Counts c = line_counts(PHASE, T.x0 + u - r, T.y0 + r, G.H, G.W, true_paths);
-      pre[q] = c.pre;
-      inv[q] = c.inv;
+      inv[q] = line_counts(PHASE, T.x0 + u - r, T.y0 + r, G.H, G.W, true_paths).inv;
     }
   }
   Row<4> LF[kT], LI[kT];
@@ -374,33 +374,32 @@ __device__ __forceinline__ void fwd_pair(const PK &K, const Row<4> (&Ef)[3], con
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc.v[k] = 0.0f;
     }
+    if (PHASE >= 2 && sp) {
+      // A tile with deferred pixels: what their sum is made of goes to the band's block (rows 0-2:
+      // the sum before pair 2 and pair 2's values; rows 3, 4: pair 3's); every other lane's stores
+      // have no address.
+      const int pix = pix_of(s_);
+      const int x = T.x0 + (pix & (kT - 1)) - (pix >> 3), y = T.y0 + (pix >> 3);
+      const int e = in_image(G, x, y) ? defer_entry(G, true_paths, x, y) : -1;
+      const unsigned o = e >= 0 ? (unsigned)(defer_in_img(G, T.i, e, PHASE == 2 ? 0 : 3) * 4) + (unsigned)L.d0 * 4u : kNowhere;
+      if (PHASE == 2) {
+        buf_store_row4<kBufSc1>(T.wsb, o, 0, acc);
+        buf_store_row4<kBufSc1>(T.wsb, o, kRowBytes, LF[s]);
+        buf_store_row4<kBufSc1>(T.wsb, o, 2 * kRowBytes, LI[s]);
+      } else {
+        buf_store_row4<kBufSc1>(T.wsb, o, 0, LF[s]);
+        buf_store_row4<kBufSc1>(T.wsb, o, kRowBytes, LI[s]);
+      }
+    }
     f32x2 lo = f32x2{acc.v[0], acc.v[1]}, hi = f32x2{acc.v[2], acc.v[3]};
     const f32x2 ilo = f32x2{LI[s].v[0], LI[s].v[1]}, ihi = f32x2{LI[s].v[2], LI[s].v[3]};
-    if (counted) {
-      const int pr = pre[q], iv = inv[q];
-      const int pa = __builtin_amdgcn_readlane(pr, 0), pb = __builtin_amdgcn_readlane(pr, 32);
-      const int ia = __builtin_amdgcn_readlane(iv, 0), ib = __builtin_amdgcn_readlane(iv, 32);
-      for (int r = 0, n = pa > pb ? pa : pb; r < n; ++r) {
-        const f32x2 l2 = lo + ilo, h2 = hi + ihi;
-        lo = r < pr ? l2 : lo;
-        hi = r < pr ? h2 : hi;
-      }
-      lo = lo + f32x2{LF[s].v[0], LF[s].v[1]};
-      hi = hi + f32x2{LF[s].v[2], LF[s].v[3]};
-      for (int r = 0, n = ia > ib ? ia : ib; r < n; ++r) {
-        const f32x2 l2 = lo + ilo, h2 = hi + ihi;
-        lo = r < iv ? l2 : lo;
-        hi = r < iv ? h2 : hi;
-      }
-    } else {
-      lo = lo + f32x2{LF[s].v[0], LF[s].v[1]};
-      hi = hi + f32x2{LF[s].v[2], LF[s].v[3]};
-      if (run_inv) {
-        const f32x2 lo2 = lo + ilo, hi2 = hi + ihi;
-        const bool r = PHASE < 2 || inv[q] != 0;
-        lo = r ? lo2 : lo;
-        hi = r ? hi2 : hi;
-      }
+    lo = lo + f32x2{LF[s].v[0], LF[s].v[1]};
+    hi = hi + f32x2{LF[s].v[2], LF[s].v[3]};
+    if (run_inv) {
+      const f32x2 lo2 = lo + ilo, hi2 = hi + ihi;
+      const bool r = PHASE < 2 || inv[q] != 0;
+      lo = r ? lo2 : lo;
+      hi = r ? hi2 : hi;
     }
     acc.v[0] = lo.x; acc.v[1] = lo.y; acc.v[2] = hi.x; acc.v[3] = hi.y;
     if (PHASE < 3 || FINAL != 0) h2_lds_store(St, saddr(s_), acc);
@@ -411,7 +410,8 @@ __device__ __forceinline__ void fwd_pair(const PK &K, const Row<4> (&Ef)[3], con
       const int pix = pix_of(s_);
       const int u = pix & (kT - 1), r = pix >> 3;
       const int x = T.x0 + u - r, y = T.y0 + r;
-      const unsigned off = (!GEN || in_image(G, x, y)) ? ((unsigned)(y * G.W + x) * (unsigned)kD + (unsigned)L.d0) * 4u : kNowhere;
+      const bool keep = (!GEN || in_image(G, x, y)) && !(sp && defer_entry(G, true_paths, x, y) >= 0);
+      const unsigned off = keep ? ((unsigned)(y * G.W + x) * (unsigned)kD + (unsigned)L.d0) * 4u : kNowhere;
       buf_store_row4<0>(T.out, off, 0, acc);
     }
   };
@@ -499,11 +499,11 @@ __device__ __forceinline__ void fwd_pair(const PK &K, const Row<4> (&Ef)[3], con
 
 template <int PHASE, int FINAL, bool GEN, typename Between>
 __device__ __forceinline__ void fwd_pair_w(int w, const PK &K, const Row<4> (&Ef)[3], const Row<4> (&Ei)[3],
-                                           Row<4> (&Xf)[3], int cls, const SkewGeom &G, const TileCtx &T,
+                                           Row<4> (&Xf)[3], int cls, bool sp, const SkewGeom &G, const TileCtx &T,
                                            int true_paths, const float *Ct, float *St, float pen, Ctx &X,
                                            const LaneId &L, Between between) {
 #define STM_FWD_PAIR(NA, NB) \
-  fwd_pair<PHASE, NA, NB, FINAL, GEN>(K, Ef, Ei, Xf, cls, G, T, true_paths, Ct, St, pen, X, L, between)
+  fwd_pair<PHASE, NA, NB, FINAL, GEN>(K, Ef, Ei, Xf, cls, sp, G, T, true_paths, Ct, St, pen, X, L, between)
   if constexpr (PHASE == 0 || PHASE == 3) {
     STM_FWD_PAIR(kT, kT);
   } else if constexpr (PHASE == 1 && kD == 128) {
@@ -658,7 +658,7 @@ __device__ __forceinline__ void publish_progress(unsigned *p, unsigned value) {
 
 // Winner takes all of the finished sum tile (tile_wta_lds with the sheared pixel positions).
 __device__ __forceinline__ void skew_wta(const float *St, int wave, int lane, const SkewGeom &G, int x0, int y0,
-                                         int32_t *__restrict__ disp) {
+                                         int32_t *__restrict__ disp, bool sp, int true_paths) {
   constexpr int LP = kWaves, NJ = kD / (LP * 4);  // lanes per pixel: a wave takes 64 / kWaves pixels
   typedef float v4f __attribute__((ext_vector_type(4)));
   const int pix = wave * (64 / LP) + lane / LP, r = lane % LP;
@@ -690,7 +690,79 @@ __device__ __forceinline__ void skew_wta(const float *St, int wave, int lane, co
   if (LP == 8) { t = dpp_i32<0x141>(k, k); k = t < k ? t : k; }
   const int u = pix & (kT - 1), rr = pix >> 3;
   const int x = x0 + u - rr, y = y0 + rr;
-  if (r == 0 && in_image(G, x, y)) disp[y * G.W + x] = k;
+  // (a deferred pixel's winner comes from finish_deferred)
+  if (r == 0 && in_image(G, x, y) && !(sp && defer_entry(G, true_paths, x, y) >= 0)) disp[y * G.W + x] = k;
+}
+
+// The deferred pixels of a band (stm_sgm_skew_index.h): S = (((S1 + [I2 x pre]) + F2) + I2 x inv2) + F3)
+// + I3 x inv3 with the reference's counts, one wave per pixel, then the finished sum and / or its
+// winner.  Run by the band's owner behind the band's last publication: off the bands' pipeline.
+template <int FINAL>
+__device__ __forceinline__ void finish_deferred(const SkewGeom &G, int true_paths, int band, BufRsrc wsb,
+                                                float *__restrict__ out, int32_t *__restrict__ disp, int wave,
+                                                int lane) {
+  constexpr int VPL = kD / 64;
+  if (!defer_line_a(G, true_paths)) return;  // (no deferred lines: square images, corrected paths)
+  const int d0 = lane * VPL;
+  for (int e = wave; e < kDeferPix; e += kWaves) {
+    int x, y;
+    if (!defer_pixel(G, true_paths, band, e, x, y)) continue;
+    Row<VPL> R[kDeferRows];
+#pragma unroll
+    for (int k = 0; k < kDeferRows; ++k) {
+      const unsigned o = (unsigned)(defer_in_img(G, band, e, k) * 4) + (unsigned)d0 * 4u;
+#if STM_SKEW_D == 256
+      R[k] = buf_load_row4<kBufSc1>(wsb, o, 0);
+#else
+      typedef unsigned v2u __attribute__((ext_vector_type(2)));
+      const v2u q = __builtin_amdgcn_raw_buffer_load_b64(wsb, (int)o, 0, kBufSc1);
+      const unsigned q0 = q.x, q1 = q.y;
+      R[k].v[0] = __builtin_bit_cast(float, q0); R[k].v[1] = __builtin_bit_cast(float, q1);
+#endif
+    }
+    const tiled::Counts c2 = line_counts(2, x, y, G.H, G.W, true_paths), c3 = line_counts(3, x, y, G.H, G.W, true_paths);
+    Row<VPL> S = R[0];
+    for (int n = 0; n < c2.pre; ++n) {
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) S.v[k] = S.v[k] + R[2].v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) S.v[k] = S.v[k] + R[1].v[k];
+    for (int n = 0; n < c2.inv; ++n) {
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) S.v[k] = S.v[k] + R[2].v[k];
+    }
+    for (int n = 0; n < c3.pre; ++n) {
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) S.v[k] = S.v[k] + R[4].v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) S.v[k] = S.v[k] + R[3].v[k];
+    for (int n = 0; n < c3.inv; ++n) {
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) S.v[k] = S.v[k] + R[4].v[k];
+    }
+    const size_t pix = (size_t)y * G.W + x;
+    if constexpr (FINAL != 2) store_row<VPL, true>(out, pix, kD, d0, S);
+    if constexpr (FINAL != 0) {
+      // Winner takes all (src/winners_take_all.cu:21-40): the first minimum of a strict '<' scan; a
+      // NaN never wins unless it is element 0.
+      float best = __builtin_inff();
+      int idx = 0;
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) {
+        const bool lt = S.v[k] < best;
+        best = lt ? S.v[k] : best;
+        idx = lt ? d0 + k : idx;
+      }
+      const float m = wave_min_f32(best);
+      int kk = best == m ? idx : 0x7fffffff;
+      kk = wave_min_i32(kk);
+      const float first = read_lane(S.v[0], 0);
+      if (first != first) kk = 0;
+      if (lane == 0) disp[pix] = kk;
+    }
+  }
 }
 
 // =====================================================================================
@@ -714,6 +786,7 @@ __device__ __forceinline__ void fwd_tile(const SkewArgs &P, const TileCtx &T, co
   const int w = L.w;
   const int cls2 = count_class(2, G, T.i, T.j, P.true_paths);
   const int cls3 = count_class(3, G, T.i, T.j, P.true_paths);
+  const bool sp = cls2 == 3 || cls3 == 3;  // the tile holds pixels of a deferred line
   // Entries of pairs 2 and 3 (a global load takes longer than a pair: pairs 0 and 1 cover them).
   const Row<4> e2t = buf_load_row4<kXSc1>(T.wsb, rowb_off(G, T, 1, T.i - 1, K2.ft, false), 0);
   const Row<4> e3t = buf_load_row4<kXSc1>(T.wsb, rowb_off(G, T, 2, T.i - 1, K3.ft, false), 0);
@@ -730,13 +803,13 @@ __device__ __forceinline__ void fwd_tile(const SkewArgs &P, const TileCtx &T, co
   // ---- pair 0: right / left
   Ef[0] = C.c0; Ef[1] = C.c0; Ef[2] = C.c0;
   Ei[0] = N.e0i; Ei[1] = N.e0i; Ei[2] = N.e0i;
-  fwd_pair_w<0, FINAL, GEN>(w, K0, Ef, Ei, Xf, 1, G, T, P.true_paths, Ct, St, pen0, X, L, [] {});
+  fwd_pair_w<0, FINAL, GEN>(w, K0, Ef, Ei, Xf, 1, false, G, T, P.true_paths, Ct, St, pen0, X, L, [] {});
   C.c0 = Xf[0];
   // ---- pair 1: down / up
   Ef[0] = sel_row(K1.carry_first, C.c1, N.e1t);
   Ef[1] = sel_row(K1.carry_first, N.e1t, C.c1);
   Ei[0] = N.e1i[0]; Ei[1] = N.e1i[1]; Ei[2] = N.e1i[1];
-  fwd_pair_w<1, FINAL, GEN>(w, K1, Ef, Ei, Xf, 1, G, T, P.true_paths, Ct, St, pen1, X, L, [&] {
+  fwd_pair_w<1, FINAL, GEN>(w, K1, Ef, Ei, Xf, 1, false, G, T, P.true_paths, Ct, St, pen1, X, L, [&] {
 #ifdef STM_SKEW_X_STATS
     const unsigned long long td0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -775,7 +848,7 @@ __device__ __forceinline__ void fwd_tile(const SkewArgs &P, const TileCtx &T, co
   if (STM_SKEW_FWD_PREFETCH_AT == 1) prefetch_next();
   // ---- pair 2: down-right / up-left
   Ef[0] = e2t; Ef[1] = C.c2a; Ef[2] = C.c2b;
-  fwd_pair_w<2, FINAL, GEN>(w, K2, Ef, Ei2, Xf, cls2, G, T, P.true_paths, Ct, St, pen2, X, L, [] { lds_barrier(); });
+  fwd_pair_w<2, FINAL, GEN>(w, K2, Ef, Ei2, Xf, cls2, sp, G, T, P.true_paths, Ct, St, pen2, X, L, [] { lds_barrier(); });
   C.c2a = Xf[0];
   C.c2b = Xf[1];  // (wave 3 has no third piece: unused there)
   // (one unconditional store: a store under a condition is a branch, behind which the compiler
@@ -784,7 +857,7 @@ __device__ __forceinline__ void fwd_tile(const SkewArgs &P, const TileCtx &T, co
   if (STM_SKEW_FWD_PREFETCH_AT == 2) prefetch_next();
   // ---- pair 3: down-left / up-right
   Ef[0] = e3t; Ef[1] = e3t; Ef[2] = e3t;
-  fwd_pair_w<3, FINAL, GEN>(w, K3, Ef, Ei3, Xf, cls3, G, T, P.true_paths, Ct, St, pen3, X, L, [] { lds_barrier(); });
+  fwd_pair_w<3, FINAL, GEN>(w, K3, Ef, Ei3, Xf, cls3, sp, G, T, P.true_paths, Ct, St, pen3, X, L, [] { lds_barrier(); });
   STM_X_STORE(buf_store_row4<kXSc1>(T.wsb, rowb_off(G, T, 2, T.i, K3.fb, true), 0, Xf[0]));
 }
 
@@ -898,11 +971,16 @@ __global__ __launch_bounds__(kThreads, kD == 128 ? 2 : 1) void sgm_skew_fwd_kern
       if (T.gen) fwd_tile<FINAL, true>(P, T, Tn, have_next, K0, K1, K2, K3, C, N, image, Ct, St, Ip, X, L, lane, publish, status);
       else fwd_tile<FINAL, false>(P, T, Tn, have_next, K0, K1, K2, K3, C, N, image, Ct, St, Ip, X, L, lane, publish, status);
       lds_barrier();
-      if constexpr (FINAL != 0) skew_wta(St, L.w, lane, G, T.x0, T.y0, disp);
+      if constexpr (FINAL != 0) {
+        const bool sp = count_class(2, G, i, j, P.true_paths) == 3 || count_class(3, G, i, j, P.true_paths) == 3;
+        skew_wta(St, L.w, lane, G, T.x0, T.y0, disp, sp, P.true_paths);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) publish_progress(prog_mine, (unsigned)G.nTC);
+    // (behind the barrier every wave's stores of the band's deferred pixels have landed)
+    finish_deferred<FINAL>(G, P.true_paths, i, T.wsb, out_all ? out_all + (size_t)b * npix * kD : nullptr, disp, L.w, lane);
   }
 }
 

@@ -41,6 +41,9 @@ using tiled::kT;                 // tile side (8)
 constexpr int kSide = 29;          // states a tile hands to its left / right neighbour (side block)
 constexpr int kHeaderFloats = 64;  // 256 bytes: status word, two unit tickets, padding
 constexpr int kTicketRev = 1, kTicketFwd = 2;  // 32-bit words of the header
+// Deferred pixels (defer_line): per band up to 8 pixels of either re-walked line, five rows each:
+// the sum before pair 2, pair 2's forward and inverse values, pair 3's.
+constexpr int kDeferPix = 16, kDeferRows = 5;
 // A progress counter has a 128-byte line to itself: a band's owner polls its neighbour's counter
 // while it waits, and with the counters of 32 bands in one line every publishing store queued up
 // behind the polls of up to 32 waiting workgroups (a single 1080p image: 40 ms instead of 13).
@@ -63,6 +66,7 @@ struct SkewGeom {
   long long img_off;    // per image: [6][nTR][W][D] row border states, then [nTR][nTC][kSide][D] side blocks
   long long img_floats;
   long long side_in_img;  // offset of the side blocks inside an image's block
+  long long defer_in_img; // [nTR][kDeferPix][kDeferRows][D]: pixels of the re-walked diagonals (deferred updates)
 };
 
 // Lays the workspace out; returns false when an image's blocks do not fit the 32-bit byte offsets
@@ -80,7 +84,8 @@ STM_HD bool make_geom(int H, int W, int D, int batch, SkewGeom &G, long long &to
   zero_floats = off;
   G.img_off = off;
   G.side_in_img = 6ll * G.nTR * W * D;
-  G.img_floats = G.side_in_img + (long long)G.nTR * G.nTC * kSide * D;
+  G.defer_in_img = G.side_in_img + (long long)G.nTR * G.nTC * kSide * D;
+  G.img_floats = G.defer_in_img + (long long)G.nTR * kDeferPix * kDeferRows * D;
   off += G.img_floats * batch;
   total_floats = off;
   const long long lim = 0xfffffff0ll;  // (offsets >= this mark "no access" in the kernels)
@@ -204,6 +209,41 @@ STM_HD int count_class(int phase, const SkewGeom &G, int i, int j, int true_path
     return (hi < G.H - 1 || lo > G.W - 1) ? 1 : 2;
   }
   return 1;
+}
+
+// ---- the re-walked diagonals ------------------------------------------------------------------------
+// The reference re-walks one inverse diagonal per family many times: on a wide
+// image (e = W - H > 0) the up-left line x - y = e and the up-right line x + y = H - 1 are added
+// 1 + e times, on a tall one (e < -1) the up-left line x - y = e is added -e - 1 times BEFORE its
+// forward pass.  Float addition has to repeat them one by one, and inside the forward pass those
+// repetitions sat on every band's critical path, one band after the other (the lines cross the
+// bands in the direction the bands depend on each other): 135 bands x 2 x ~150 us on a 1080p
+// image.  The forward pass therefore DEFERS these pixels: it saves what their final sum is made of
+// (the sum before pair 2 and the four values of pairs 2 and 3) and the band's owner finishes them
+// when the band is done and published, off the pipeline.
+// Which lines are deferred: A (pair 2) / B (pair 3).
+STM_HD bool defer_line_a(const SkewGeom &G, int true_paths) { return !true_paths && (G.W - G.H > 0 || G.W - G.H < -1); }
+STM_HD bool defer_line_b(const SkewGeom &G, int true_paths) { return !true_paths && G.W - G.H > 0; }
+STM_HD bool on_line_a(const SkewGeom &G, int x, int y) { return x - y == G.W - G.H; }
+STM_HD bool on_line_b(const SkewGeom &G, int x, int y) { return x + y == G.H - 1; }
+// Entry of a deferred pixel in its band's block: 0..7 line A by row of the band, 8..15 line B; -1: not deferred.
+STM_HD int defer_entry(const SkewGeom &G, int true_paths, int x, int y) {
+  if (defer_line_a(G, true_paths) && on_line_a(G, x, y)) return y & (kT - 1);
+  if (defer_line_b(G, true_paths) && on_line_b(G, x, y)) return kT + (y & (kT - 1));
+  return -1;
+}
+STM_HD long long defer_in_img(const SkewGeom &G, int t, int entry, int row) {
+  return G.defer_in_img + (((long long)t * kDeferPix + entry) * kDeferRows + row) * (long long)G.D;
+}
+// Pixel of an entry of band t; false: the entry is empty (outside the image, line not deferred, or
+// -- line B -- the pixel lies on line A as well and is entry A's).
+STM_HD bool defer_pixel(const SkewGeom &G, int true_paths, int t, int entry, int &x, int &y) {
+  y = kT * t + (entry & (kT - 1));
+  const bool a = entry < kT;
+  if (a ? !defer_line_a(G, true_paths) : !defer_line_b(G, true_paths)) return false;
+  x = a ? y + (G.W - G.H) : G.H - 1 - y;
+  if (!in_image(G, x, y)) return false;
+  return a || !(defer_line_a(G, true_paths) && on_line_a(G, x, y));
 }
 
 // ---- what a tile reads and writes outside itself ---------------------------------------------
