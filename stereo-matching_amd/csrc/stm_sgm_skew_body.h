@@ -42,11 +42,6 @@ constexpr int kSumPixBytes = st_stride(kD) * 4;
 constexpr int kIpW = kT + 4;                 // intensity patch: u in [-2, 9], r in [-1, 8]
 constexpr int kIpN = kIpW * (kT + 2);
 
-#ifdef STM_SKEW_X_STATS
-__device__ unsigned long long g_skew_pub[256];   // band 0 of the forward pass: when value k was published
-__device__ unsigned long long g_skew_see[512];   // band 1: [2 k] when tile k started, [2 k + 1] the counter value it had seen by then
-__device__ unsigned long long g_skew_stamps[8192];  // [band][8]: forward pass, image 0: start of tiles 0, 1, 2, 4, 8, 32, 128, last
-#endif
 struct SkewArgs {
   SkewGeom G;
   float p1, p2;
@@ -634,13 +629,6 @@ __device__ __forceinline__ void wait_progress(const unsigned *p, unsigned need, 
   for (unsigned trip = 1;; ++trip) {
     __builtin_amdgcn_s_sleep(STM_SKEW_POLL_SLEEP);
     seen = poll_counter(p);
-#ifdef STM_SKEW_X_STATS  // header words 8..: waits that looped, polls, 10-ns ticks waited
-    if ((threadIdx.x & 63) == 0) atomicAdd(status + 9, 1u);
-    if (seen >= need && (threadIdx.x & 63) == 0) {
-      atomicAdd(status + 8, 1u);
-      atomicAdd(status + 10, (unsigned)(__builtin_amdgcn_s_memrealtime() - t0));
-    }
-#endif
     if (seen >= need) return;
     // (the status word is ONE line for the whole chip: looked at every 256th trip only)
     if ((trip & 255u) != 0u) continue;
@@ -781,7 +769,7 @@ template <int FINAL, bool GEN>
 __device__ __forceinline__ void fwd_tile(const SkewArgs &P, const TileCtx &T, const TileCtx &Tn, bool have_next,
                                          const PK &K0, const PK &K1, const PK &K2, const PK &K3, FwdCarry &C,
                                          FwdPre &N, const float *image, float *Ct, float *St, const float *Ip,
-                                         Ctx &X, const LaneId &L, int lane, unsigned *publish, unsigned *stats) {
+                                         Ctx &X, const LaneId &L, int lane, unsigned *publish) {
   const SkewGeom &G = P.G;
   const int w = L.w;
   const int cls2 = count_class(2, G, T.i, T.j, P.true_paths);
@@ -810,26 +798,11 @@ __device__ __forceinline__ void fwd_tile(const SkewArgs &P, const TileCtx &T, co
   Ef[1] = sel_row(K1.carry_first, N.e1t, C.c1);
   Ei[0] = N.e1i[0]; Ei[1] = N.e1i[1]; Ei[2] = N.e1i[1];
   fwd_pair_w<1, FINAL, GEN>(w, K1, Ef, Ei, Xf, 1, false, G, T, P.true_paths, Ct, St, pen1, X, L, [&] {
-#ifdef STM_SKEW_X_STATS
-    const unsigned long long td0 = __builtin_amdgcn_s_memrealtime();
-#endif
 #ifndef STM_SKEW_X_NODRAIN
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores of the previous tile have landed
 #endif
-#ifdef STM_SKEW_X_STATS
-    const unsigned long long td1 = __builtin_amdgcn_s_memrealtime();
-#endif
     lds_barrier();
-#ifdef STM_SKEW_X_STATS
-    if (threadIdx.x == 0) {
-      atomicAdd(stats + 11, (unsigned)(td1 - td0));
-      atomicAdd(stats + 12, (unsigned)(__builtin_amdgcn_s_memrealtime() - td1));
-    }
-#endif
     if (publish && threadIdx.x == 0) publish_progress(publish, (unsigned)T.j);
-#ifdef STM_SKEW_X_STATS
-    if (threadIdx.x == 0 && T.i == 0 && T.j < 256) g_skew_pub[T.j] = __builtin_amdgcn_s_memrealtime();
-#endif
   });
   {
     const bool main_diag = !K1.restart1;
@@ -926,18 +899,7 @@ __global__ __launch_bounds__(kThreads, kD == 128 ? 2 : 1) void sgm_skew_fwd_kern
       make_tile(T, G, i, j);
       const bool have_next = j + 1 < G.nTC;
       make_tile(Tn, G, i, have_next ? j + 1 : j);
-#ifdef STM_SKEW_X_STATS
-      const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
-      if (threadIdx.x == 0 && b == 0 && i < 1024) {
-        const int k = j == 0 ? 0 : (j == 1 ? 1 : (j == 2 ? 2 : (j == 4 ? 3 : (j == 8 ? 4 : (j == 32 ? 5 : (j == 128 ? 6 : (j == G.nTC - 1 ? 7 : -1)))))));
-        if (k >= 0) g_skew_stamps[i * 8 + k] = ts0;
-      }
-#endif
       stage_cost(N.cost, Ct, Ip, L);
-#ifdef STM_SKEW_X_STATS
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      const unsigned long long ts1 = __builtin_amdgcn_s_memrealtime();
-#endif
       // The band above is far enough ahead for this tile's entries and the next tile's prefetch.
       // `ahead`: the counter as requested a tile ago -- a band that follows its neighbour closely
       // needs a new value every tile, and a poll at this point is a memory round trip on the
@@ -948,28 +910,14 @@ __global__ __launch_bounds__(kThreads, kD == 128 ? 2 : 1) void sgm_skew_fwd_kern
         seen = ahead > seen ? ahead : seen;
         wait_progress(prog_above, (unsigned)progress_needed(G, j), seen, status, dead);
       }
-#ifdef STM_SKEW_X_STATS
-      const unsigned long long ts2 = __builtin_amdgcn_s_memrealtime();
-#endif
-#ifdef STM_SKEW_X_STATS
-      if (threadIdx.x == 0 && i == 1 && j < 256) { g_skew_see[2 * j] = __builtin_amdgcn_s_memrealtime(); g_skew_see[2 * j + 1] = seen; }
-#endif
       lds_barrier();
       if (L.w == 0 && i > 0) ahead = poll_counter(prog_above);  // (looked at at the top of the next tile)
-#ifdef STM_SKEW_X_STATS
-      if (threadIdx.x == 0 && j > 0) {
-        atomicAdd(status + 13, (unsigned)(ts1 - ts0));
-        atomicAdd(status + 14, (unsigned)(ts2 - ts1));
-        atomicAdd(status + 15, (unsigned)(__builtin_amdgcn_s_memrealtime() - ts2));
-        atomicAdd(status + 16, 1u);
-      }
-#endif
       // (the band's own progress -- tiles < j are complete -- is published behind pair 1's barrier,
       // in front of which every wave drains its stores: by then the previous tile's last stores
       // have had a pair's time, a drain at the top of the tile would wait for them)
       unsigned *publish = j > 0 ? prog_mine : nullptr;
-      if (T.gen) fwd_tile<FINAL, true>(P, T, Tn, have_next, K0, K1, K2, K3, C, N, image, Ct, St, Ip, X, L, lane, publish, status);
-      else fwd_tile<FINAL, false>(P, T, Tn, have_next, K0, K1, K2, K3, C, N, image, Ct, St, Ip, X, L, lane, publish, status);
+      if (T.gen) fwd_tile<FINAL, true>(P, T, Tn, have_next, K0, K1, K2, K3, C, N, image, Ct, St, Ip, X, L, lane, publish);
+      else fwd_tile<FINAL, false>(P, T, Tn, have_next, K0, K1, K2, K3, C, N, image, Ct, St, Ip, X, L, lane, publish);
       lds_barrier();
       if constexpr (FINAL != 0) {
         const bool sp = count_class(2, G, i, j, P.true_paths) == 3 || count_class(3, G, i, j, P.true_paths) == 3;
@@ -1190,14 +1138,3 @@ int skew_launch_d256
 
 }  // namespace stm
 
-#ifdef STM_SKEW_X_STATS
-#if STM_SKEW_D == 128
-extern "C" int stm_debug_skew_stamps_d128(unsigned long long *dst) {
-#else
-extern "C" int stm_debug_skew_stamps_d256(unsigned long long *dst) {
-#endif
-  hipMemcpyFromSymbol(dst + 8192, HIP_SYMBOL(stm::g_skew_pub), sizeof(unsigned long long) * 256);
-  hipMemcpyFromSymbol(dst + 8192 + 256, HIP_SYMBOL(stm::g_skew_see), sizeof(unsigned long long) * 512);
-  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(stm::g_skew_stamps), sizeof(unsigned long long) * 8192);
-}
-#endif

@@ -118,9 +118,16 @@ SgmForm sgm_form(int H, int W, int D, int batch, int flags) {
   //   tiles behind walks       0.233  0.228  0.234  0.218
   //   tiles behind sweeps      0.266  0.191  0.176  0.163  0.154
   //   skewed tiles             0.360  0.201  0.148  0.132  0.127
+  //   1080p, D = 256           8      16     32          (tools/sgm_forms.py)
+  //   tiles behind sweeps      3.74   3.65   3.59
+  //   skewed tiles             3.87   3.41   3.10
+  // (D = 256: one workgroup per CU, so eight 1080p pairs are 1,080 bands for 256 workgroups -- five
+  // rounds for 4.2 rounds of work, and a band is a serial chain of 241 tiles that no finer unit
+  // shortens: band segments were built and measured, 40.6 against 30.9 ms)
   if (!(flags & (STM_SGM_PAIRED | STM_SGM_TILED | STM_SGM_WALKS)) && skew_covers(H, W, D, batch, flags)) {
     const int cus = device_cus();
-    if (cus > 0 && (long long)batch * ((H + kT - 1) / kT) >= 8ll * cus && W >= 64) return kSgmSkew;
+    const long long bands = (long long)batch * ((H + kT - 1) / kT), wgs = (long long)cus * (D == 128 ? 2 : 1);
+    if (cus > 0 && bands >= (D == 128 ? 4 : 6) * wgs && W >= 64) return kSgmSkew;
   }
   if (!shape_ok(H, W, D, batch, flags)) return kSgmPaired;
   TiledGeom G;
