@@ -14,6 +14,9 @@ namespace {
 using namespace skew;
 using std::integral_constant;
 
+#ifndef STM_SKEW_FWD_ENTRIES_AT
+#define STM_SKEW_FWD_ENTRIES_AT 0
+#endif
 #ifndef STM_SKEW_FWD_PREFETCH_AT
 #define STM_SKEW_FWD_PREFETCH_AT 2  // the next tile's cost rows are requested behind pair 1 / pair 2
 #endif
@@ -34,6 +37,7 @@ constexpr int kXSc1 = kBufSc1;
 #else
 #define STM_X_STORE(...) __VA_ARGS__
 #endif
+static_assert(kNowhere == kNoAccess, "one 'no access' offset");
 constexpr int kD = STM_SKEW_D;              // 128: two chains per wave (half-waves), four waves per tile;
 constexpr int kWaves = kD == 128 ? 4 : 8;    // 256: one chain per wave, eight waves per tile
 constexpr int kThreads = kWaves * 64;
@@ -98,137 +102,28 @@ __device__ __forceinline__ Row<4> step1(const Row<4> &p, const Row<4> &c, float 
 
 // Per-lane constants of a pair: the lane's chain.  Pieces are in SLOT order (which for pair 1's
 // second half-wave is B before A, so that both halves of a wave change piece at the same slot).
-struct PK {
-  int pix[3];       // r * 8 + u of the first slot of each piece
-  unsigned ft;      // forward pass: top entry of the forward chain (row border states; relative)
-  unsigned fb;      // forward pass: bottom exit of the forward chain
-  unsigned ie[3];   // forward pass: entry of the inverse chain per piece: relative | 1 = side block
-  unsigned rb;      // reverse pass: bottom entry of the inverse chain
-  unsigned rt;      // reverse pass: top exit of the inverse chain
-  unsigned rs[3];   // reverse pass: left exit per piece (side block; kNowhere: none)
-  bool carry_first; // pair 1: the first piece in slot order is the one that enters from the left
-  bool restart1;    // the second piece begins at an entry state (false: the main diagonal continues)
-  bool e0_bottom;   // pair 1, reverse pass: the first piece in slot order enters from the band below
-};
-
-// Relative byte offsets: a row border state at image column x = 8 j + xr is ((xr + 8) * D + d0) * 4
-// from the state of column 8 j - 8 in the same line; a side state is (idx * D + d0) * 4 into its block.
-__device__ __forceinline__ unsigned rel_row(int xr, int d0) { return (unsigned)(((xr + kT) * kD + d0) * 4); }
-__device__ __forceinline__ unsigned rel_side(int idx, int d0) { return (unsigned)((idx * kD + d0) * 4) | 1u; }
-
+// Per-lane constants of a pair (the lane's chain: skew::ChainIO, stm_sgm_skew_index.h).
+typedef ChainIO PK;
 template <int PHASE>
 __device__ __forceinline__ void pk_init(PK &K, const LaneId &L) {
-  const int d0 = L.d0;
-  K.carry_first = false;
-  K.restart1 = true;
-  K.e0_bottom = false;
-  K.ft = K.fb = K.rb = K.rt = kNowhere;
-#pragma unroll
-  for (int q = 0; q < 3; ++q) { K.pix[q] = 0; K.ie[q] = kNowhere; K.rs[q] = kNowhere; }
-  if constexpr (PHASE == 0) {
-    const int k = L.row;
-    K.pix[0] = k * kT;
-    K.ie[0] = rel_side(side_idx_left(k), d0);
-    K.rs[0] = rel_side(side_idx_left(k), d0);
-  } else if constexpr (PHASE == 3) {
-    const int k = L.row;
-    K.pix[0] = k;
-    K.ft = rel_row(k + 1, d0);      // state of down-left after (x + 1, y0 - 1)
-    K.fb = rel_row(k - 7, d0);      // ... after the column's last pixel (k, 7): x = 8 j + k - 7
-    K.ie[0] = rel_row(k - 8, d0);   // up-right after (x - 1, y0 + 8)
-    K.rb = K.ie[0];
-    K.rt = rel_row(k, d0);          // up-right after (k, 0)
-  } else if constexpr (PHASE == 1) {
-    // D = 128: half-wave 0 of wave w owns chain w + 1 (A then B), half-wave 1 chain 7 - w in the order
-    // B, A (both halves then change piece at slot 7 - w); wave 3's second half the main diagonal,
-    // cut into 4 + 4 that continue.  D = 256: wave w owns chain w; the main diagonal is one piece.
-    const bool main_diag = kD == 128 ? (L.half == 1 && L.w == 3) : L.w == 0;
-    const int c = kD == 128 ? (L.half == 0 ? L.w + 1 : (main_diag ? 0 : 7 - L.w)) : L.w;
-    const Chain ch = chain_of(1, c);
-    const int pa = ch.p[0].r * kT + ch.p[0].u, pb = ch.p[1].r * kT + ch.p[1].u;
-    if (main_diag) {
-      K.pix[0] = 0; K.pix[1] = 4 * kT + 4;
-      K.restart1 = false;
-      K.ft = rel_row(0, d0); K.fb = rel_row(0, d0);
-      K.ie[kD == 128 ? 1 : 0] = rel_row(0, d0);  // (the piece the inverse chain enters at the bottom)
-      K.e0_bottom = kD != 128;
-      K.rb = rel_row(0, d0); K.rt = rel_row(0, d0);
-    } else {
-      K.carry_first = kD == 128 && L.half == 1;
-      K.e0_bottom = K.carry_first;
-      K.pix[0] = K.carry_first ? pb : pa;
-      K.pix[1] = K.carry_first ? pa : pb;
-      K.ft = rel_row(c, d0);        // down after (x = 8 j + c, y0 - 1)
-      K.fb = rel_row(c - 8, d0);    // ... after B's last pixel (c - 1, 7): x = 8 j + c - 8
-      const unsigned side = rel_side(side_idx_up(kT - c), d0), bot = rel_row(c - 8, d0);
-      K.ie[0] = K.carry_first ? bot : side;
-      K.ie[1] = K.carry_first ? side : bot;
-      K.rb = bot;
-      K.rt = rel_row(c, d0);
-      K.rs[0] = K.carry_first ? side : kNowhere;  // B leaves to the left at (0, 8 - c)
-      K.rs[1] = K.carry_first ? kNowhere : side;
-    }
-  } else {
-    const int c0 = 7 - L.row;
-    const Chain ch = chain_of(2, c0);
-    int ul = 0;  // u of the chain's last pixel (row 7)
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      if (q < ch.np) {
-        K.pix[q] = ch.p[q].r * kT + ch.p[q].u;
-        const int ue = ch.p[q].u + 2 * (ch.p[q].n - 1), re = ch.p[q].r + ch.p[q].n - 1;  // its last pixel
-        if (q == ch.np - 1) {
-          ul = ue;
-        } else {
-          // the inverse chain enters from (ue + 2, re + 1), pixel (ue - 6, re + 1) of the tile on the right
-          K.ie[q] = rel_side(side_idx_upleft(ue + 2 - kT, re + 1), d0);
-        }
-        if (q > 0) K.rs[q] = rel_side(side_idx_upleft(ch.p[q].u, ch.p[q].r), d0);  // leaves to the left at its first pixel
-      }
-    }
-    K.ft = rel_row(c0 - 1, d0);           // down-right after (x - 1, y0 - 1)
-    K.fb = rel_row(ul - 7, d0);           // ... after the last pixel (ul, 7)
-    K.ie[ch.np - 1] = rel_row(ul - 6, d0);  // up-left after (x + 1, y0 + 8)
-    K.rb = K.ie[ch.np - 1];
-    K.rt = rel_row(c0, d0);               // up-left after (c0, 0)
-  }
+  chain_io(kD, PHASE, L.w, L.half, L.d0, K);
 }
 
 // Where a tile's accesses go: descriptors over the image's cost volume, output and workspace
-// block, and the tile's terms of the offsets.
-struct TileCtx {
+// block, and the tile's terms of the offsets (skew::TilePos).
+struct TileCtx : TilePos {
   BufRsrc cost, out, wsb;
-  int i, j;         // band, tile column
-  int x0, y0;
-  bool gen;         // not a fast tile: validity per lane
 };
-
-// Byte offset (inside the image's workspace block) of a row border state given its relative
-// offset; kNowhere when it does not exist (gen tiles only).
+// (the offsets themselves: row_state_off / side_state_off / fwd_inverse_entry_off, stm_sgm_skew_index.h)
 __device__ __forceinline__ unsigned rowb_off(const SkewGeom &G, const TileCtx &T, int dir, int t, unsigned rel,
                                              bool need_row7) {
-  if (rel >= kNowhere) return kNowhere;
-  if (!T.gen) return rel + (unsigned)(rowb_in_img(G, dir, t, T.x0 - kT) * 4);
-  const int xr = (int)(rel / (unsigned)kRowBytes) - kT, x = T.x0 + xr;
-  bool ok = rel != kNowhere && x >= 0 && x < G.W && t >= 0 && t < G.nTR;
-  if (need_row7) ok = ok && kT * t + kT - 1 < G.H;
-  return ok ? (unsigned)(rowb_in_img(G, dir, t, x) * 4) + rel % (unsigned)kRowBytes : kNowhere;
+  return row_state_off(G, T, dir, t, rel, need_row7);
 }
 __device__ __forceinline__ unsigned side_off(const SkewGeom &G, const TileCtx &T, int jb, unsigned rel) {
-  if (rel >= kNowhere) return kNowhere;
-  const unsigned r = rel & ~1u;
-  if (!T.gen) return r + (unsigned)(side_in_img(G, T.i, jb, 0) * 4);
-  const bool ok = jb >= 1 && jb < G.nTC;
-  return ok ? r + (unsigned)(side_in_img(G, T.i, jb, 0) * 4) : kNowhere;
+  return side_state_off(G, T, jb, rel);
 }
-// An inverse-chain entry of the forward pass: side block of tile j + 1 or row states of band i + 1.
 __device__ __forceinline__ unsigned fwd_ie_off(const SkewGeom &G, const TileCtx &T, int dir, unsigned e) {
-  if (e >= kNowhere) return kNowhere;
-  if (!T.gen) {
-    const unsigned base = (e & 1u) ? (unsigned)(side_in_img(G, T.i, T.j + 1, 0) * 4) : (unsigned)(rowb_in_img(G, dir, T.i + 1, T.x0 - kT) * 4);
-    return (e & ~1u) + base;
-  }
-  return (e & 1u) ? side_off(G, T, T.j + 1, e) : rowb_off(G, T, dir, T.i + 1, e, false);
+  return fwd_inverse_entry_off(G, T, dir, e);
 }
 
 // ---- cost tile, intensities ---------------------------------------------------------------------
@@ -530,14 +425,8 @@ __device__ __forceinline__ void fwd_pair_w(int w, const PK &K, const Row<4> (&Ef
 #undef STM_FWD_PAIR
 }
 // Slots at which wave w's chains of a pair change piece.
-__device__ __forceinline__ int na_of(int phase, int w) {
-  if (kD == 128) return phase == 1 ? 7 - w : (phase == 2 ? w + 1 : kT);
-  return phase == 1 ? (w == 0 ? kT : kT - w) : (phase == 2 ? (w >> 1) + 1 : kT);
-}
-__device__ __forceinline__ int nb_of(int phase, int w) {
-  const int g = kD == 128 ? w : w >> 1;
-  return phase == 2 && g < 3 ? g + 5 : kT;
-}
+__device__ __forceinline__ int na_of(int phase, int w) { return skew::na_of(kD, phase, w); }
+__device__ __forceinline__ int nb_of(int phase, int w) { return skew::nb_of(kD, phase, w); }
 
 // =====================================================================================
 // Reverse pass: the inverse chains of TWO pairs of a tile for one wave, stepped together (slot
@@ -775,14 +664,21 @@ __device__ __forceinline__ void fwd_tile(const SkewArgs &P, const TileCtx &T, co
   const int cls2 = count_class(2, G, T.i, T.j, P.true_paths);
   const int cls3 = count_class(3, G, T.i, T.j, P.true_paths);
   const bool sp = cls2 == 3 || cls3 == 3;  // the tile holds pixels of a deferred line
-  // Entries of pairs 2 and 3 (a global load takes longer than a pair: pairs 0 and 1 cover them).
-  const Row<4> e2t = buf_load_row4<kXSc1>(T.wsb, rowb_off(G, T, 1, T.i - 1, K2.ft, false), 0);
-  const Row<4> e3t = buf_load_row4<kXSc1>(T.wsb, rowb_off(G, T, 2, T.i - 1, K3.ft, false), 0);
-  Row<4> Ei2[3], Ei3[3];
+  // Entries of pairs 2 and 3 (a global load takes longer than a pair: they are requested a pair
+  // or two ahead; STM_SKEW_FWD_ENTRIES_AT: at the top of the tile, or pair 2's behind pair 0 and
+  // pair 3's behind pair 1 -- fewer registers held through the first pairs).
+  Row<4> e2t, e3t, Ei2[3], Ei3[3];
+  auto load_e2 = [&] {
+    e2t = buf_load_row4<kXSc1>(T.wsb, rowb_off(G, T, 1, T.i - 1, K2.ft, false), 0);
 #pragma unroll
-  for (int q = 0; q < 3; ++q) Ei2[q] = buf_load_row4<0>(T.wsb, fwd_ie_off(G, T, 4, K2.ie[q]), 0);
-  Ei3[0] = buf_load_row4<0>(T.wsb, fwd_ie_off(G, T, 5, K3.ie[0]), 0);
-  Ei3[1] = Ei3[0]; Ei3[2] = Ei3[0];
+    for (int q = 0; q < 3; ++q) Ei2[q] = buf_load_row4<0>(T.wsb, fwd_ie_off(G, T, 4, K2.ie[q]), 0);
+  };
+  auto load_e3 = [&] {
+    e3t = buf_load_row4<kXSc1>(T.wsb, rowb_off(G, T, 2, T.i - 1, K3.ft, false), 0);
+    Ei3[0] = buf_load_row4<0>(T.wsb, fwd_ie_off(G, T, 5, K3.ie[0]), 0);
+    Ei3[1] = Ei3[0]; Ei3[2] = Ei3[0];
+  };
+  if (STM_SKEW_FWD_ENTRIES_AT == 0) { load_e2(); load_e3(); }
   const float pen0 = chain_penalties<0, -1, 0, 1>(K0, kT, kT, K0, kT, kT, Ip, P.p1, P.p2, lane);
   const float pen1 = chain_penalties<1, -1, 1, 1>(K1, na_of(1, w), kT, K1, na_of(1, w), kT, Ip, P.p1, P.p2, lane);
   const float pen2 = chain_penalties<2, -1, 2, 1>(K2, na_of(2, w), nb_of(2, w), K2, na_of(2, w), nb_of(2, w), Ip, P.p1, P.p2, lane);
@@ -793,6 +689,7 @@ __device__ __forceinline__ void fwd_tile(const SkewArgs &P, const TileCtx &T, co
   Ei[0] = N.e0i; Ei[1] = N.e0i; Ei[2] = N.e0i;
   fwd_pair_w<0, FINAL, GEN>(w, K0, Ef, Ei, Xf, 1, false, G, T, P.true_paths, Ct, St, pen0, X, L, [] {});
   C.c0 = Xf[0];
+  if (STM_SKEW_FWD_ENTRIES_AT == 1) load_e2();
   // ---- pair 1: down / up
   Ef[0] = sel_row(K1.carry_first, C.c1, N.e1t);
   Ef[1] = sel_row(K1.carry_first, N.e1t, C.c1);
@@ -819,6 +716,7 @@ __device__ __forceinline__ void fwd_tile(const SkewArgs &P, const TileCtx &T, co
     N.e1i[1] = buf_load_row4<0>(Tn.wsb, fwd_ie_off(G, Tn, 3, K1.ie[1]), 0);
   };
   if (STM_SKEW_FWD_PREFETCH_AT == 1) prefetch_next();
+  if (STM_SKEW_FWD_ENTRIES_AT == 1) load_e3();
   // ---- pair 2: down-right / up-left
   Ef[0] = e2t; Ef[1] = C.c2a; Ef[2] = C.c2b;
   fwd_pair_w<2, FINAL, GEN>(w, K2, Ef, Ei2, Xf, cls2, sp, G, T, P.true_paths, Ct, St, pen2, X, L, [] { lds_barrier(); });
@@ -835,9 +733,7 @@ __device__ __forceinline__ void fwd_tile(const SkewArgs &P, const TileCtx &T, co
 }
 
 __device__ __forceinline__ void make_tile(TileCtx &T, const SkewGeom &G, int i, int j) {
-  T.i = i; T.j = j;
-  T.x0 = kT * j; T.y0 = kT * i;
-  T.gen = !tile_fast(G, i, j);
+  make_tile_pos(T, G, i, j);
 #ifdef STM_SKEW_X_NOGEN  // (timing experiment: every tile takes the fast form; results are wrong)
   T.gen = false;
 #endif

@@ -174,6 +174,157 @@ STM_HD Chain chain_of(int phase, int k) {
   return c;
 }
 
+// ---- a lane's chain of a pair: where its pieces lie and what it loads and stores ------------------
+// D = 128: two chains per wave (half-waves: lanes 0-31 / 32-63), four waves per tile; D = 256: one
+// chain per wave, eight waves.  Pieces are in SLOT order (which for pair 1's second half-wave at
+// D = 128 is B before A, so that both halves of a wave change piece at the same slot).
+// Relative byte offsets: a row border state at image column x = 8 j + xr is ((xr + 8) * D + d0) * 4
+// from the state of column 8 j - 8 in the same line; a side state is ((idx * D + d0) * 4) | 1 into
+// its block.  kNoAccess: none (an offset beyond every buffer: the hardware drops the access).
+constexpr unsigned kNoAccess = 0xfffffff0u;
+struct ChainIO {
+  int pix[3];       // r * 8 + u of the first slot of each piece
+  unsigned ft;      // forward pass: top entry of the forward chain (row border states; relative)
+  unsigned fb;      // forward pass: bottom exit of the forward chain
+  unsigned ie[3];   // forward pass: entry of the inverse chain per piece: relative | 1 = side block
+  unsigned rb;      // reverse pass: bottom entry of the inverse chain
+  unsigned rt;      // reverse pass: top exit of the inverse chain
+  unsigned rs[3];   // reverse pass: left exit per piece (side block; kNoAccess: none)
+  bool carry_first; // pair 1: the first piece in slot order is the one that enters from the left
+  bool restart1;    // the second piece begins at an entry state (false: the main diagonal continues)
+  bool e0_bottom;   // pair 1, reverse pass: the first piece in slot order enters from the band below
+};
+STM_HD unsigned rel_row(int D, int xr, int d0) { return (unsigned)(((xr + kT) * D + d0) * 4); }
+STM_HD unsigned rel_side(int D, int idx, int d0) { return (unsigned)((idx * D + d0) * 4) | 1u; }
+// The chain of the simple pairs (tile row of pair 0, tile column of pair 3) of wave w / half-wave.
+STM_HD int lane_row(int D, int w, int half) { return D == 128 ? 2 * w + half : w; }
+STM_HD void chain_io(int D, int phase, int w, int half, int d0, ChainIO &K) {
+  const int row = lane_row(D, w, half);
+  K.carry_first = false;
+  K.restart1 = true;
+  K.e0_bottom = false;
+  K.ft = K.fb = K.rb = K.rt = kNoAccess;
+  for (int q = 0; q < 3; ++q) { K.pix[q] = 0; K.ie[q] = kNoAccess; K.rs[q] = kNoAccess; }
+  if (phase == 0) {
+    const int k = row;
+    K.pix[0] = k * kT;
+    K.ie[0] = rel_side(D, side_idx_left(k), d0);
+    K.rs[0] = rel_side(D, side_idx_left(k), d0);
+  } else if (phase == 3) {
+    const int k = row;
+    K.pix[0] = k;
+    K.ft = rel_row(D, k + 1, d0);      // state of down-left after (x + 1, y0 - 1)
+    K.fb = rel_row(D, k - 7, d0);      // ... after the column's last pixel (k, 7): x = 8 j + k - 7
+    K.ie[0] = rel_row(D, k - 8, d0);   // up-right after (x - 1, y0 + 8)
+    K.rb = K.ie[0];
+    K.rt = rel_row(D, k, d0);          // up-right after (k, 0)
+  } else if (phase == 1) {
+    // D = 128: half-wave 0 of wave w owns chain w + 1 (A then B), half-wave 1 chain 7 - w in the order
+    // B, A (both halves then change piece at slot 7 - w); wave 3's second half the main diagonal,
+    // cut into 4 + 4 that continue.  D = 256: wave w owns chain w; the main diagonal is one piece.
+    const bool main_diag = D == 128 ? (half == 1 && w == 3) : w == 0;
+    const int c = D == 128 ? (half == 0 ? w + 1 : (main_diag ? 0 : 7 - w)) : w;
+    const Chain ch = chain_of(1, c);
+    const int pa = ch.p[0].r * kT + ch.p[0].u, pb = ch.p[1].r * kT + ch.p[1].u;
+    if (main_diag) {
+      K.pix[0] = 0; K.pix[1] = 4 * kT + 4;
+      K.restart1 = false;
+      K.ft = rel_row(D, 0, d0); K.fb = rel_row(D, 0, d0);
+      if (D == 128) K.ie[1] = rel_row(D, 0, d0);  // (the piece the inverse chain enters at the bottom)
+      else K.ie[0] = rel_row(D, 0, d0);
+      K.e0_bottom = D != 128;
+      K.rb = rel_row(D, 0, d0); K.rt = rel_row(D, 0, d0);
+    } else {
+      K.carry_first = D == 128 && half == 1;
+      K.e0_bottom = K.carry_first;
+      K.pix[0] = K.carry_first ? pb : pa;
+      K.pix[1] = K.carry_first ? pa : pb;
+      K.ft = rel_row(D, c, d0);        // down after (x = 8 j + c, y0 - 1)
+      K.fb = rel_row(D, c - 8, d0);    // ... after B's last pixel (c - 1, 7): x = 8 j + c - 8
+      const unsigned side = rel_side(D, side_idx_up(kT - c), d0), bot = rel_row(D, c - 8, d0);
+      K.ie[0] = K.carry_first ? bot : side;
+      K.ie[1] = K.carry_first ? side : bot;
+      K.rb = bot;
+      K.rt = rel_row(D, c, d0);
+      K.rs[0] = K.carry_first ? side : kNoAccess;  // B leaves to the left at (0, 8 - c)
+      K.rs[1] = K.carry_first ? kNoAccess : side;
+    }
+  } else {
+    const int c0 = 7 - row;
+    const Chain ch = chain_of(2, c0);
+    int ul = 0;  // u of the chain's last pixel (row 7)
+    unsigned last_entry = kNoAccess;
+    for (int q = 0; q < 3; ++q) {
+      if (q < ch.np) {
+        K.pix[q] = ch.p[q].r * kT + ch.p[q].u;
+        const int ue = ch.p[q].u + 2 * (ch.p[q].n - 1), re = ch.p[q].r + ch.p[q].n - 1;  // its last pixel
+        if (q == ch.np - 1) {
+          ul = ue;
+        } else {
+          // the inverse chain enters from (ue + 2, re + 1), pixel (ue - 6, re + 1) of the tile on the right
+          K.ie[q] = rel_side(D, side_idx_upleft(ue + 2 - kT, re + 1), d0);
+        }
+        if (q > 0) K.rs[q] = rel_side(D, side_idx_upleft(ch.p[q].u, ch.p[q].r), d0);  // leaves to the left at its first pixel
+      }
+    }
+    last_entry = rel_row(D, ul - 6, d0);     // up-left after (x + 1, y0 + 8)
+    K.ft = rel_row(D, c0 - 1, d0);           // down-right after (x - 1, y0 - 1)
+    K.fb = rel_row(D, ul - 7, d0);           // ... after the last pixel (ul, 7)
+    if (ch.np == 3) K.ie[2] = last_entry; else K.ie[1] = last_entry;
+    K.rb = last_entry;
+    K.rt = rel_row(D, c0, d0);               // up-left after (c0, 0)
+  }
+}
+// Slots at which a chain of wave w changes piece (the same for both half-waves at D = 128).
+STM_HD int na_of(int D, int phase, int w) {
+  if (D == 128) return phase == 1 ? 7 - w : (phase == 2 ? w + 1 : kT);
+  return phase == 1 ? (w == 0 ? kT : kT - w) : (phase == 2 ? (w >> 1) + 1 : kT);
+}
+STM_HD int nb_of(int D, int phase, int w) {
+  const int g = D == 128 ? w : w >> 1;
+  return phase == 2 && g < 3 ? g + 5 : kT;
+}
+
+// ---- a tile's terms of the offsets -----------------------------------------------------------------
+struct TilePos {
+  int i, j;   // band, tile column
+  int x0, y0;
+  bool gen;   // not a fast tile: validity per lane
+};
+STM_HD void make_tile_pos(TilePos &T, const SkewGeom &G, int i, int j) {
+  T.i = i; T.j = j;
+  T.x0 = kT * j; T.y0 = kT * i;
+  T.gen = !tile_fast(G, i, j);
+}
+// Byte offset (inside the image's workspace block) of a row border state given its relative
+// offset; kNoAccess when it does not exist (gen tiles only).  need_row7: a state after the
+// band's LAST row (the forward pass's bottom exits), which a partial band does not have.
+STM_HD unsigned row_state_off(const SkewGeom &G, const TilePos &T, int dir, int t, unsigned rel, bool need_row7) {
+  if (rel >= kNoAccess) return kNoAccess;
+  const unsigned row_bytes = (unsigned)G.D * 4u;
+  if (!T.gen) return rel + (unsigned)(rowb_in_img(G, dir, t, T.x0 - kT) * 4);
+  const int xr = (int)(rel / row_bytes) - kT, x = T.x0 + xr;
+  bool ok = x >= 0 && x < G.W && t >= 0 && t < G.nTR;
+  if (need_row7) ok = ok && kT * t + kT - 1 < G.H;
+  return ok ? (unsigned)(rowb_in_img(G, dir, t, x) * 4) + rel % row_bytes : kNoAccess;
+}
+STM_HD unsigned side_state_off(const SkewGeom &G, const TilePos &T, int jb, unsigned rel) {
+  if (rel >= kNoAccess) return kNoAccess;
+  const unsigned r = rel & ~1u;
+  if (!T.gen) return r + (unsigned)(side_in_img(G, T.i, jb, 0) * 4);
+  const bool ok = jb >= 1 && jb < G.nTC;
+  return ok ? r + (unsigned)(side_in_img(G, T.i, jb, 0) * 4) : kNoAccess;
+}
+// An inverse-chain entry of the forward pass: side block of tile j + 1 or row states of band i + 1.
+STM_HD unsigned fwd_inverse_entry_off(const SkewGeom &G, const TilePos &T, int dir, unsigned e) {
+  if (e >= kNoAccess) return kNoAccess;
+  if (!T.gen) {
+    const unsigned base = (e & 1u) ? (unsigned)(side_in_img(G, T.i, T.j + 1, 0) * 4) : (unsigned)(rowb_in_img(G, dir, T.i + 1, T.x0 - kT) * 4);
+    return (e & ~1u) + base;
+  }
+  return (e & 1u) ? side_state_off(G, T, T.j + 1, e) : row_state_off(G, T, dir, T.i + 1, e, false);
+}
+
 // How the inverse passes of the line through image pixel (gx, gy) count.
 STM_HD tiled::Counts line_counts(int phase, int gx, int gy, int H, int W, int true_paths) {
   tiled::TiledGeom T;

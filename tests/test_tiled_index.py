@@ -7,6 +7,11 @@
   border-state blocks, mailboxes, outputs), clamped prefetches and dummy entry reads included.
 * The generated code of the sweep kernels re-issues the mailbox load on every trip of a wait
   loop (the polling load must not be hoisted out of it).
+* ``tests/host/skew_index_check.cpp`` replays the DATAFLOW of the skewed-tile form
+  (``csrc/stm_sgm_skew_index.h``) symbolically: every state the two passes store gets the label
+  (direction, pixel, producing tile); every entry state they load must find the label the
+  recurrence needs at its address, produced by a tile the progress rule has waited for; every
+  address lies inside the image's workspace block.
 """
 import os
 import re
@@ -26,6 +31,37 @@ def test_every_tiled_kernel_address_lies_inside_its_buffer(tmp_path):
     assert m and int(m.group(1)) == 14 * 14 * 3 * 2 and int(m.group(2)) > 10 ** 9, out.stdout
 
 
+def test_skewed_tile_dataflow_is_consistent(tmp_path):
+    """Stores and loads of the skewed-tile form meet: right state at every address, producers
+    covered by progress_needed(), everything inside the block, chains tile the tiles -- for 330
+    shapes (H, W in {1,2,7,8,9,15,16,17,40,95,151,375,450}, D in {128, 256}).  Mutations of the
+    header (a shifted offset, a wrong side index, a shorter lead) make it fail."""
+    exe = str(tmp_path / "skew_index_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Werror", "-I", CSRC,
+                           os.path.join(ROOT, "tests", "host", "skew_index_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    m = re.match(r"(\d+) shapes, (\d+) checks, 0 failures", out.stdout.strip().splitlines()[-1])
+    assert m and int(m.group(1)) == 330 and int(m.group(2)) > 10 ** 7, out.stdout
+    # the check has teeth: a bottom exit shifted by one column must be caught
+    hdr = open(os.path.join(CSRC, "stm_sgm_skew_index.h")).read()
+    bad = hdr.replace("K.fb = rel_row(D, c - 8, d0);", "K.fb = rel_row(D, c - 7, d0);")
+    assert bad != hdr
+    mut = tmp_path / "mut"
+    mut.mkdir()
+    (mut / "stm_sgm_skew_index.h").write_text(bad)
+    (mut / "stm_sgm_tiled_index.h").write_text(open(os.path.join(CSRC, "stm_sgm_tiled_index.h")).read())
+    exe2 = str(tmp_path / "skew_index_check_mut")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", str(mut),
+                           os.path.join(ROOT, "tests", "host", "skew_index_check.cpp"), "-o", exe2])
+    assert subprocess.run([exe2], capture_output=True, text=True).returncode != 0
+    # ... and the kernels form none of these offsets by hand
+    body = open(os.path.join(CSRC, "stm_sgm_skew_body.h")).read()
+    code = "\n".join(line.split("//")[0] for line in body.splitlines())
+    for pattern in ("rowb_in_img(", "side_in_img(", "G.nTC *", "* G.nTC", "kSide"):
+        assert pattern not in code, "stm_sgm_skew_body.h forms a state address by hand (%r)" % pattern
+
+
 def test_kernels_use_the_index_header_for_their_addresses():
     """The kernels' files form no border-state or mailbox address by hand: the expressions the
     range model covers are the only ones (a guard against the model and the kernels drifting
@@ -39,19 +75,24 @@ def test_kernels_use_the_index_header_for_their_addresses():
         assert "kMboxSlots *" not in code and "% kMboxSlots" not in code, name + ": mailbox index formed by hand"
 
 
-def test_mailbox_poll_is_reissued_inside_the_wait_loop(tmp_path):
-    """ISA of the sweep kernels: every spin loop (s_sleep) contains a load with the sc1 policy
-    before its backward branch -- the poll is not hoisted out of the loop."""
+import pytest
+
+
+@pytest.mark.parametrize("unit,least", [("stm_sgm_sweep.hip", 12), ("stm_sgm_skew_d128.hip", 4)])
+def test_mailbox_poll_is_reissued_inside_the_wait_loop(tmp_path, unit, least):
+    """ISA of the sweep kernels (mailboxes) and of the skewed-tile kernels (progress counters):
+    every spin loop (s_sleep) contains a load with the sc1 policy before its backward branch --
+    the poll is not hoisted out of the loop."""
     hipcc = "/opt/rocm/bin/hipcc"
-    asm = str(tmp_path / "sweep.s")
+    asm = str(tmp_path / "unit.s")
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                            "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
                            "-I", os.path.join(ROOT, "include"), "-I", CSRC, "--cuda-device-only", "-S",
-                           os.path.join(CSRC, "stm_sgm_sweep.hip"), "-o", asm],
+                           os.path.join(CSRC, unit), "-o", asm],
                           stderr=subprocess.DEVNULL)
     lines = open(asm).read().splitlines()
     sleeps = [i for i, l in enumerate(lines) if re.match(r"\s*s_sleep\b", l)]
-    assert len(sleeps) >= 12, "expected the wait loops of six sweep kernels"
+    assert len(sleeps) >= least, "expected the wait loops of the unit's kernels"
     for i in sleeps:
         body = []
         for l in lines[i + 1:i + 80]:
@@ -78,9 +119,14 @@ def test_register_soffset_buffer_stores_hold_their_data(tmp_path):
     pads the store-data hazard only for immediate soffsets, and on gfx950 the next VALU write
     to the data registers otherwise races with the store's read of them."""
     hipcc = "/opt/rocm/bin/hipcc"
-    checked = ("stm_sgm_sweep.hip", "stm_sgm_hwalk.hip", "stm_dp.hip")
+    checked = ("stm_sgm_sweep.hip", "stm_sgm_hwalk.hip", "stm_dp.hip", "stm_sgm_skew_d128.hip", "stm_sgm_skew_d256.hip")
     for f in os.listdir(CSRC):  # every unit that stores through a descriptor is in the list
-        if f.endswith(".hip") and re.search(r"raw_buffer_store|buf_store_row", open(os.path.join(CSRC, f)).read()):
+        if not f.endswith(".hip"):
+            continue
+        src = open(os.path.join(CSRC, f)).read()
+        for inc in re.findall(r'#include "(stm_sgm_skew_body\.h)"', src):  # (a unit that is its body header)
+            src += open(os.path.join(CSRC, inc)).read()
+        if f.endswith(".hip") and re.search(r"raw_buffer_store|buf_store_row", src):
             assert f in checked, f + " stores through a buffer descriptor: add it to this test"
     for name in checked:
         asm = str(tmp_path / (name + ".s"))
