@@ -94,12 +94,19 @@ def main():
                            "form": "tiled (sweeps)" if k.startswith("sgm_hwalk") else
                                    ("tiled (walks)" if k.startswith("sgm_bwalk") else "paired")}
                     groups.append(cur)
+                if k.startswith("sgm_skew_rev_kernel"):
+                    # (the skewed-tile form: reverse pass, then forward pass; both disparity counts'
+                    # kernels carry the same name -- four waves per workgroup at D = 128, eight at 256)
+                    wg = int(r.get("Workgroup_Size", r.get("Workgroup_Size_X", "256")))
+                    cur = {"vpl": "skew<%d>" % (2 if wg == 256 else 4), "bytes": 0.0, "fused": False,
+                           "form": "skewed tiles"}
+                    groups.append(cur)
                 if cur is None:
                     continue
                 cur["bytes"] += float(r["Counter_Value"]) * 1024.0 * scale
-                if k.startswith(("sgm_pair_kernel", "sgm_tile_kernel", "sgm_tile_h2_kernel")):
+                if k.startswith(("sgm_pair_kernel", "sgm_tile_kernel", "sgm_tile_h2_kernel", "sgm_skew_fwd_kernel")):
                     args = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")]
-                    if k.startswith("sgm_tile_h2_kernel"):  # <FINAL> (D = 128)
+                    if k.startswith(("sgm_tile_h2_kernel", "sgm_skew_fwd_kernel")):  # <FINAL>
                         final = args[0]
                     else:
                         final = args[3] if k.startswith("sgm_pair_kernel") and len(args) >= 4 else args[1]
