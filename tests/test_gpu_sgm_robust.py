@@ -242,6 +242,40 @@ def test_tiled_call_beside_a_kernel_that_holds_cus(device, hold_ms, fraction):
     assert torch.equal(again, ref)
 
 
+@pytest.mark.parametrize("hold_ms,fraction", [(300, 1.0), (3500, 0.5)])
+def test_skewed_tiles_beside_a_kernel_that_holds_cus(device, hold_ms, fraction):
+    """The skewed-tile form has no residency requirement: its units are taken by ticket, so
+    whatever a workgroup waits for is held by a workgroup that runs.  A kernel that holds all CUs
+    for 0.3 s, or half of them for 3.5 s (longer than the bounded waits), only delays it: status 0
+    and the right map either way; and two such calls on two streams run side by side."""
+    import stereomatch
+    hold = _hold_lib()
+    H, W, D, B = 96, 640, 128, 26
+    rng = np.random.default_rng(29)
+    C = torch.from_numpy((rng.random((B, H, W, D)) * 50).astype(np.float32)).to(device)
+    I = torch.from_numpy(rng.integers(0, 6, size=(B, H, W)).astype(np.float32)).to(device)
+    ref = stereomatch.aggregation.Semiglobal(form="paired").aggregate_and_reduce(C, I)[1]
+    sgm = stereomatch.aggregation.Semiglobal(form="skew")
+    warm = sgm.aggregate_and_reduce(C, I)[1]
+    assert sgm._last_form == stereomatch._native.STM_SGM_FORM_SKEW and sgm.status() == 0 and torch.equal(warm, ref)
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    side = torch.cuda.Stream(device)
+    torch.cuda.synchronize()
+    assert hold.stm_test_hold_cus(int(cus * fraction), hold_ms, side.cuda_stream) == 0
+    time.sleep(0.05)
+    out = sgm.aggregate_and_reduce(C, I)[1].clone()
+    assert sgm.status() == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    # two calls in flight on two streams (each with its own op, i.e. its own workspace)
+    other = stereomatch.aggregation.Semiglobal(form="skew")
+    with torch.cuda.stream(side):
+        a = other.aggregate_and_reduce(C, I)[1]
+    b = sgm.aggregate_and_reduce(C, I)[1]
+    torch.cuda.synchronize()
+    assert other.status() == 0 and sgm.status() == 0 and torch.equal(a, ref) and torch.equal(b, ref)
+
+
 def test_failed_call_is_reported_by_the_next_call(device):
     """The deferred report: a set status word raises at the start of the next call on the same
     op (no blocking), with the recovery named."""
