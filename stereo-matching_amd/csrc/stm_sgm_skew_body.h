@@ -106,7 +106,7 @@ __device__ __forceinline__ Row<4> step1(const Row<4> &p, const Row<4> &c, float 
 typedef ChainIO PK;
 template <int PHASE>
 __device__ __forceinline__ void pk_init(PK &K, const LaneId &L) {
-  chain_io(kD, PHASE, L.w, L.half, L.d0, K);
+  chain_io_t<PHASE>(kD, L.w, L.half, L.d0, K);
 }
 
 // Where a tile's accesses go: descriptors over the image's cost volume, output and workspace
@@ -433,7 +433,7 @@ __device__ __forceinline__ int nb_of(int phase, int w) { return skew::nb_of(kD, 
 // 7 - s of both).  Ea / Eb: entry states per piece; Xa / Xb: the chain's state after each piece
 // (in slot order: X[q] is the state after the piece's FIRST slot, where the inverse chain leaves it).
 // =====================================================================================
-template <int PA, int NAA, int NBA, int PB, int NAB, int NBB, bool GEN>
+template <int PA, int NAA, int NBA, int PB, int NAB, int NBB>
 __device__ __forceinline__ void rev_pairs(const PK &KA, const Row<4> (&Ea)[3], Row<4> (&Xa)[3], const PK &KB,
                                           const Row<4> (&Eb)[3], Row<4> (&Xb)[3], const SkewGeom &G,
                                           const TileCtx &T, const float *Ct, float pen, Ctx &X,
@@ -452,7 +452,10 @@ __device__ __forceinline__ void rev_pairs(const PK &KA, const Row<4> (&Ea)[3], R
     return KB.pix[q] + (s - st) * tile_pstep(PB);
   };
   unsigned bia = 0, bib = 0, unused_f;
-  if constexpr (GEN) {
+  // (one copy of the code for clipped and full tiles: in the reverse pass two instantiations side
+  // by side bought nothing)
+  const bool gen = T.gen;
+  if (gen) {
     begin_masks<PA, NAA, NBA>(KA, G, T, unused_f, bia);
     begin_masks<PB, NAB, NBB>(KB, G, T, unused_f, bib);
   }
@@ -471,7 +474,7 @@ __device__ __forceinline__ void rev_pairs(const PK &KA, const Row<4> (&Ea)[3], R
       cbn = h2_lds_row(Ct, pix_b(integral_constant<int, r - 1>()) * kRowBytes + hl16);
     }
     step2<r, 8 + r>(pa, ca, pb, cb, pen, X, XB);
-    if constexpr (GEN) {
+    if (gen) {
       pa = sel_row(((bia >> r) & 1u) != 0u, ca, pa);
       pb = sel_row(((bib >> r) & 1u) != 0u, cb, pb);
     }
@@ -755,8 +758,8 @@ __global__ __launch_bounds__(kThreads, kD == 128 ? 2 : 1) void sgm_skew_fwd_kern
   L.init();
   Ctx X;
   ctx_init(X, P.p1, L, P.dlim);
-  PK K0, K1, K2, K3;
-  pk_init<0>(K0, L); pk_init<1>(K1, L); pk_init<2>(K2, L); pk_init<3>(K3, L);
+  PK K0, K1, K2m, K3;
+  pk_init<0>(K0, L); pk_init<1>(K1, L); pk_init<2>(K2m, L); pk_init<3>(K3, L);
   unsigned *status = reinterpret_cast<unsigned *>(ws);
   unsigned *prog = reinterpret_cast<unsigned *>(ws + G.prog_off);
   const size_t npix = (size_t)G.H * G.W;
@@ -812,6 +815,16 @@ __global__ __launch_bounds__(kThreads, kD == 128 ? 2 : 1) void sgm_skew_fwd_kern
       // in front of which every wave drains its stores: by then the previous tile's last stores
       // have had a pair's time, a drain at the top of the tile would wait for them)
       unsigned *publish = j > 0 ? prog_mine : nullptr;
+      // Pair 2's per-lane constants are read from (scratch) MEMORY, through a pointer the compiler
+      // cannot see through and that is new every tile (else it hoists the loads out of the loop,
+      // back into registers): the kernel runs at the 256-register limit, and with these eight in
+      // registers hipcc spills ~100 others around the tile loop (24.9 against 21.7 ms per 256 Teddy
+      // pairs; all four pairs' constants in memory: 28.7 -- the scratch loads of the other pairs'
+      // slot addresses are then on the chains' way; the reverse pass, which has registers to
+      // spare, keeps them all in registers).
+      const PK *k2p = &K2m;
+      asm volatile("" : "+v"(k2p));
+      const PK &K2 = *k2p;
       if (T.gen) fwd_tile<FINAL, true>(P, T, Tn, have_next, K0, K1, K2, K3, C, N, image, Ct, St, Ip, X, L, lane, publish);
       else fwd_tile<FINAL, false>(P, T, Tn, have_next, K0, K1, K2, K3, C, N, image, Ct, St, Ip, X, L, lane, publish);
       lds_barrier();
@@ -847,7 +860,6 @@ __device__ __forceinline__ void rev_bottoms(RevPre &N, const SkewGeom &G, const 
   N.b3 = buf_load_row4<kXSc1>(T.wsb, rowb_off(G, T, 5, T.i + 1, K3.rb, false), 0);
 }
 
-template <bool GEN>
 __device__ __forceinline__ void rev_tile(const SkewArgs &P, const TileCtx &T, const TileCtx &Tn, const PK &K0,
                                          const PK &K1, const PK &K2, const PK &K3, RevCarry &C, RevPre &N,
                                          const float *image, const float *Ct, const float *Ip, Ctx &X,
@@ -864,7 +876,7 @@ __device__ __forceinline__ void rev_tile(const SkewArgs &P, const TileCtx &T, co
   Eb[0] = sel_row(K1.e0_bottom, b1, C.c1);
   Eb[1] = sel_row(K1.carry_first, C.c1, b1);
   Eb[2] = b1;
-#define STM_REV01(NA) rev_pairs<0, kT, kT, 1, NA, kT, GEN>(K0, Ea, Xa, K1, Eb, Xb, G, T, Ct, pen01, X, L)
+#define STM_REV01(NA) rev_pairs<0, kT, kT, 1, NA, kT>(K0, Ea, Xa, K1, Eb, Xb, G, T, Ct, pen01, X, L)
   if constexpr (kD == 128) {
     switch (w) {
       case 0: STM_REV01(7); break;
@@ -914,7 +926,7 @@ __device__ __forceinline__ void rev_tile(const SkewArgs &P, const TileCtx &T, co
   Eb[0] = b3; Eb[1] = b3; Eb[2] = b3;
   const bool three = nb_of(2, w) < kT;  // the chain has a third piece
   Ea[0] = C.c2a; Ea[1] = sel_row(three, C.c2b, b2); Ea[2] = b2;
-#define STM_REV23(NA, NB) rev_pairs<2, NA, NB, 3, kT, kT, GEN>(K2, Ea, Xa, K3, Eb, Xb, G, T, Ct, pen23, X, L)
+#define STM_REV23(NA, NB) rev_pairs<2, NA, NB, 3, kT, kT>(K2, Ea, Xa, K3, Eb, Xb, G, T, Ct, pen23, X, L)
   switch (kD == 128 ? w : w >> 1) {
     case 0: STM_REV23(1, 5); break;
     case 1: STM_REV23(2, 6); break;
@@ -991,8 +1003,7 @@ __global__ __launch_bounds__(kThreads, kD == 128 ? STM_SKEW_REV_OCC : 1) void sg
       lds_barrier();
       if (L.w == 0 && below) ahead = poll_counter(prog_below);
       unsigned *publish = jj > 0 ? prog_mine : nullptr;
-      if (T.gen) rev_tile<true>(P, T, Tn, K0, K1, K2, K3, C, N, image, Ct, Ip, X, L, lane, publish, (unsigned)jj);
-      else rev_tile<false>(P, T, Tn, K0, K1, K2, K3, C, N, image, Ct, Ip, X, L, lane, publish, (unsigned)jj);
+      rev_tile(P, T, Tn, K0, K1, K2, K3, C, N, image, Ct, Ip, X, L, lane, publish, (unsigned)jj);
       lds_barrier();  // (the next tile's staging overwrites the cost tile)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -31,6 +31,14 @@
 
 #include "stm_sgm_tiled_index.h"  // STM_HD, imin_/imax_, Counts/seg_counts
 
+// Loops over a chain's (at most three) pieces must be unrolled in device code: an array indexed
+// by a loop variable lives in scratch memory.
+#if defined(__HIPCC__)
+#define STM_UNROLL _Pragma("unroll")
+#else
+#define STM_UNROLL
+#endif
+
 namespace stm {
 namespace skew {
 
@@ -198,19 +206,25 @@ STM_HD unsigned rel_row(int D, int xr, int d0) { return (unsigned)(((xr + kT) * 
 STM_HD unsigned rel_side(int D, int idx, int d0) { return (unsigned)((idx * D + d0) * 4) | 1u; }
 // The chain of the simple pairs (tile row of pair 0, tile column of pair 3) of wave w / half-wave.
 STM_HD int lane_row(int D, int w, int half) { return D == 128 ? 2 * w + half : w; }
-STM_HD void chain_io(int D, int phase, int w, int half, int d0, ChainIO &K) {
+// (a template over the pair: with a run-time `phase` hipcc kept the unused branches' values alive
+// around the kernels' tile loops -- 111 instead of 19 spilled registers in the forward pass)
+template <int PHASE>
+STM_HD void chain_io_t(int D, int w, int half, int d0, ChainIO &K) {
   const int row = lane_row(D, w, half);
   K.carry_first = false;
   K.restart1 = true;
   K.e0_bottom = false;
   K.ft = K.fb = K.rb = K.rt = kNoAccess;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
   for (int q = 0; q < 3; ++q) { K.pix[q] = 0; K.ie[q] = kNoAccess; K.rs[q] = kNoAccess; }
-  if (phase == 0) {
+  if constexpr (PHASE == 0) {
     const int k = row;
     K.pix[0] = k * kT;
     K.ie[0] = rel_side(D, side_idx_left(k), d0);
     K.rs[0] = rel_side(D, side_idx_left(k), d0);
-  } else if (phase == 3) {
+  } else if constexpr (PHASE == 3) {
     const int k = row;
     K.pix[0] = k;
     K.ft = rel_row(D, k + 1, d0);      // state of down-left after (x + 1, y0 - 1)
@@ -218,7 +232,7 @@ STM_HD void chain_io(int D, int phase, int w, int half, int d0, ChainIO &K) {
     K.ie[0] = rel_row(D, k - 8, d0);   // up-right after (x - 1, y0 + 8)
     K.rb = K.ie[0];
     K.rt = rel_row(D, k, d0);          // up-right after (k, 0)
-  } else if (phase == 1) {
+  } else if constexpr (PHASE == 1) {
     // D = 128: half-wave 0 of wave w owns chain w + 1 (A then B), half-wave 1 chain 7 - w in the order
     // B, A (both halves then change piece at slot 7 - w); wave 3's second half the main diagonal,
     // cut into 4 + 4 that continue.  D = 256: wave w owns chain w; the main diagonal is one piece.
@@ -254,6 +268,9 @@ STM_HD void chain_io(int D, int phase, int w, int half, int d0, ChainIO &K) {
     const Chain ch = chain_of(2, c0);
     int ul = 0;  // u of the chain's last pixel (row 7)
     unsigned last_entry = kNoAccess;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
     for (int q = 0; q < 3; ++q) {
       if (q < ch.np) {
         K.pix[q] = ch.p[q].r * kT + ch.p[q].u;
@@ -274,6 +291,12 @@ STM_HD void chain_io(int D, int phase, int w, int half, int d0, ChainIO &K) {
     K.rb = last_entry;
     K.rt = rel_row(D, c0, d0);               // up-left after (c0, 0)
   }
+}
+STM_HD void chain_io(int D, int phase, int w, int half, int d0, ChainIO &K) {
+  if (phase == 0) chain_io_t<0>(D, w, half, d0, K);
+  else if (phase == 1) chain_io_t<1>(D, w, half, d0, K);
+  else if (phase == 2) chain_io_t<2>(D, w, half, d0, K);
+  else chain_io_t<3>(D, w, half, d0, K);
 }
 // Slots at which a chain of wave w changes piece (the same for both half-waves at D = 128).
 STM_HD int na_of(int D, int phase, int w) {
@@ -301,12 +324,13 @@ STM_HD void make_tile_pos(TilePos &T, const SkewGeom &G, int i, int j) {
 // band's LAST row (the forward pass's bottom exits), which a partial band does not have.
 STM_HD unsigned row_state_off(const SkewGeom &G, const TilePos &T, int dir, int t, unsigned rel, bool need_row7) {
   if (rel >= kNoAccess) return kNoAccess;
-  const unsigned row_bytes = (unsigned)G.D * 4u;
   if (!T.gen) return rel + (unsigned)(rowb_in_img(G, dir, t, T.x0 - kT) * 4);
-  const int xr = (int)(rel / row_bytes) - kT, x = T.x0 + xr;
+  // (D is 128 or 256: a row of 512 or 1,024 bytes -- shifts, not a division by a run-time value)
+  const int sh = G.D == 128 ? 9 : 10;
+  const int xr = (int)(rel >> sh) - kT, x = T.x0 + xr;
   bool ok = x >= 0 && x < G.W && t >= 0 && t < G.nTR;
   if (need_row7) ok = ok && kT * t + kT - 1 < G.H;
-  return ok ? (unsigned)(rowb_in_img(G, dir, t, x) * 4) + rel % row_bytes : kNoAccess;
+  return ok ? (unsigned)(rowb_in_img(G, dir, t, x) * 4) + (rel & ((1u << sh) - 1u)) : kNoAccess;
 }
 STM_HD unsigned side_state_off(const SkewGeom &G, const TilePos &T, int jb, unsigned rel) {
   if (rel >= kNoAccess) return kNoAccess;
