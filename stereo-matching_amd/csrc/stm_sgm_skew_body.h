@@ -51,7 +51,23 @@ struct SkewArgs {
   float p1, p2;
   int dlim;
   int true_paths;
+#ifdef STM_SKEW_STAMPS
+  unsigned long long *stamps;  // [tile column][wave][16] s_memtime stamps of one band of image 0
+  int stamp_band;
+#endif
 };
+// Diagnostic build (-DSTM_SKEW_STAMPS, tools/skew_stamps.py): where a tile's time goes.
+#ifdef STM_SKEW_STAMPS
+unsigned long long *g_skew_stamps = nullptr;
+int g_skew_stamp_band = 0;
+#define STM_SK_STAMP(k)                                                                                  \
+  do {                                                                                                   \
+    if (T.stamp && (threadIdx.x & 63) == 0)                                                              \
+      P.stamps[((size_t)T.j * kWaves + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_amdgcn_s_memtime();  \
+  } while (0)
+#else
+#define STM_SK_STAMP(k) do {} while (0)
+#endif
 
 struct LaneId {
   int w, half, hl, d0, hl16;
@@ -109,10 +125,60 @@ __device__ __forceinline__ void pk_init(PK &K, const LaneId &L) {
   chain_io_t<PHASE>(kD, L.w, L.half, L.d0, K);
 }
 
+// Forward pass: the chains' constants live in LDS, not in registers.  The kernel runs at the
+// 256-register limit; with the ~20 constants in registers hipcc spills ~100 others around the tile
+// loop, and a scratch access is a vector-memory access: its s_waitcnt vmcnt waits for every global
+// load issued before it -- the entry states and the next tile's cost rows, requested a pair or two
+// ahead ON PURPOSE -- so each spill reload on the way costs a memory round trip (s_memtime stamps,
+// tools/skew_stamps.py: 15 of a tile's 43 thousand clocks).  An LDS read waits for LDS reads only.
+// One row of kKtN words per (pair, half-wave), written once per workgroup from chain_io_t with
+// d0 = 0; a lane's offset is the row's + 4 d0 (saturating: kNoAccess stays "no access").
+constexpr int kKtN = 12;
+constexpr int kKtWords = 4 * kWaves * 2 * kKtN;
+template <int PHASE>
+__device__ __forceinline__ void kt_fill(unsigned *Kt, const LaneId &L) {
+  PK K;
+  chain_io_t<PHASE>(kD, L.w, L.half, 0, K);
+  if (L.hl == 0) {
+    unsigned *row = Kt + ((PHASE * kWaves + L.w) * 2 + L.half) * kKtN;
+    row[0] = (unsigned)K.pix[0]; row[1] = (unsigned)K.pix[1]; row[2] = (unsigned)K.pix[2];
+    row[3] = (K.carry_first ? 1u : 0u) | (K.restart1 ? 2u : 0u);
+    row[4] = K.ft; row[5] = K.fb; row[6] = 0u; row[7] = 0u;
+    row[8] = K.ie[0]; row[9] = K.ie[1]; row[10] = K.ie[2]; row[11] = 0u;
+  }
+}
+// A fetch of a pair's constants (what the caller does not use is not loaded); every fetch is a new
+// one: nothing of an earlier fetch stays in registers for it.
+template <int PHASE>
+__device__ __forceinline__ PK kt_fetch(const unsigned *Kt, const LaneId &L) {
+  unsigned o = (unsigned)(((PHASE * kWaves + L.w) * 2 + L.half) * kKtN);
+  asm volatile("" : "+v"(o));
+  const unsigned *row = Kt + o;
+  const unsigned d = (unsigned)L.hl16;
+  PK K;
+  K.pix[0] = (int)row[0]; K.pix[1] = (int)row[1]; K.pix[2] = (int)row[2];
+  const unsigned fl = row[3];
+  K.carry_first = (fl & 1u) != 0u;
+  K.restart1 = (fl & 2u) != 0u;
+  K.e0_bottom = false;
+  K.ft = __builtin_elementwise_add_sat(row[4], d);
+  K.fb = __builtin_elementwise_add_sat(row[5], d);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    K.ie[q] = __builtin_elementwise_add_sat(row[8 + q], d);
+    K.rs[q] = kNoAccess;
+  }
+  K.rb = K.rt = kNoAccess;
+  return K;
+}
+
 // Where a tile's accesses go: descriptors over the image's cost volume, output and workspace
 // block, and the tile's terms of the offsets (skew::TilePos).
 struct TileCtx : TilePos {
   BufRsrc cost, out, wsb;
+#ifdef STM_SKEW_STAMPS
+  bool stamp;
+#endif
 };
 // (the offsets themselves: row_state_off / side_state_off / fwd_inverse_entry_off, stm_sgm_skew_index.h)
 __device__ __forceinline__ unsigned rowb_off(const SkewGeom &G, const TileCtx &T, int dir, int t, unsigned rel,
@@ -659,7 +725,7 @@ struct FwdPre {
 
 template <int FINAL, bool GEN>
 __device__ __forceinline__ void fwd_tile(const SkewArgs &P, const TileCtx &T, const TileCtx &Tn, bool have_next,
-                                         const PK &K0, const PK &K1, const PK &K2, const PK &K3, FwdCarry &C,
+                                         const unsigned *Kt, FwdCarry &C,
                                          FwdPre &N, const float *image, float *Ct, float *St, const float *Ip,
                                          Ctx &X, const LaneId &L, int lane, unsigned *publish) {
   const SkewGeom &G = P.G;
@@ -672,67 +738,84 @@ __device__ __forceinline__ void fwd_tile(const SkewArgs &P, const TileCtx &T, co
   // pair 3's behind pair 1 -- fewer registers held through the first pairs).
   Row<4> e2t, e3t, Ei2[3], Ei3[3];
   auto load_e2 = [&] {
+    const PK K2 = kt_fetch<2>(Kt, L);
     e2t = buf_load_row4<kXSc1>(T.wsb, rowb_off(G, T, 1, T.i - 1, K2.ft, false), 0);
 #pragma unroll
     for (int q = 0; q < 3; ++q) Ei2[q] = buf_load_row4<0>(T.wsb, fwd_ie_off(G, T, 4, K2.ie[q]), 0);
   };
   auto load_e3 = [&] {
+    const PK K3 = kt_fetch<3>(Kt, L);
     e3t = buf_load_row4<kXSc1>(T.wsb, rowb_off(G, T, 2, T.i - 1, K3.ft, false), 0);
     Ei3[0] = buf_load_row4<0>(T.wsb, fwd_ie_off(G, T, 5, K3.ie[0]), 0);
     Ei3[1] = Ei3[0]; Ei3[2] = Ei3[0];
   };
   if (STM_SKEW_FWD_ENTRIES_AT == 0) { load_e2(); load_e3(); }
-  const float pen0 = chain_penalties<0, -1, 0, 1>(K0, kT, kT, K0, kT, kT, Ip, P.p1, P.p2, lane);
-  const float pen1 = chain_penalties<1, -1, 1, 1>(K1, na_of(1, w), kT, K1, na_of(1, w), kT, Ip, P.p1, P.p2, lane);
-  const float pen2 = chain_penalties<2, -1, 2, 1>(K2, na_of(2, w), nb_of(2, w), K2, na_of(2, w), nb_of(2, w), Ip, P.p1, P.p2, lane);
-  const float pen3 = chain_penalties<3, -1, 3, 1>(K3, kT, kT, K3, kT, kT, Ip, P.p1, P.p2, lane);
+  float pen0, pen1, pen2, pen3;
+  {
+    const PK K0 = kt_fetch<0>(Kt, L), K1 = kt_fetch<1>(Kt, L), K2 = kt_fetch<2>(Kt, L), K3 = kt_fetch<3>(Kt, L);
+    pen0 = chain_penalties<0, -1, 0, 1>(K0, kT, kT, K0, kT, kT, Ip, P.p1, P.p2, lane);
+    pen1 = chain_penalties<1, -1, 1, 1>(K1, na_of(1, w), kT, K1, na_of(1, w), kT, Ip, P.p1, P.p2, lane);
+    pen2 = chain_penalties<2, -1, 2, 1>(K2, na_of(2, w), nb_of(2, w), K2, na_of(2, w), nb_of(2, w), Ip, P.p1, P.p2, lane);
+    pen3 = chain_penalties<3, -1, 3, 1>(K3, kT, kT, K3, kT, kT, Ip, P.p1, P.p2, lane);
+  }
   Row<4> Ef[3], Ei[3], Xf[3];
   // ---- pair 0: right / left
   Ef[0] = C.c0; Ef[1] = C.c0; Ef[2] = C.c0;
   Ei[0] = N.e0i; Ei[1] = N.e0i; Ei[2] = N.e0i;
-  fwd_pair_w<0, FINAL, GEN>(w, K0, Ef, Ei, Xf, 1, false, G, T, P.true_paths, Ct, St, pen0, X, L, [] {});
+  STM_SK_STAMP(2);
+  fwd_pair_w<0, FINAL, GEN>(w, kt_fetch<0>(Kt, L), Ef, Ei, Xf, 1, false, G, T, P.true_paths, Ct, St, pen0, X, L, [] {});
+  STM_SK_STAMP(3);
   C.c0 = Xf[0];
   if (STM_SKEW_FWD_ENTRIES_AT == 1) load_e2();
   // ---- pair 1: down / up
+  const PK K1 = kt_fetch<1>(Kt, L);
   Ef[0] = sel_row(K1.carry_first, C.c1, N.e1t);
   Ef[1] = sel_row(K1.carry_first, N.e1t, C.c1);
   Ei[0] = N.e1i[0]; Ei[1] = N.e1i[1]; Ei[2] = N.e1i[1];
   fwd_pair_w<1, FINAL, GEN>(w, K1, Ef, Ei, Xf, 1, false, G, T, P.true_paths, Ct, St, pen1, X, L, [&] {
+    STM_SK_STAMP(4);
 #ifndef STM_SKEW_X_NODRAIN
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores of the previous tile have landed
 #endif
+    STM_SK_STAMP(5);
     lds_barrier();
+    STM_SK_STAMP(6);
     if (publish && threadIdx.x == 0) publish_progress(publish, (unsigned)T.j);
   });
+  STM_SK_STAMP(7);
   {
-    const bool main_diag = !K1.restart1;
-    C.c1 = sel_row(K1.carry_first, Xf[1], Xf[0]);
-    const Row<4> bottom = sel_row(K1.carry_first && !main_diag, Xf[0], Xf[1]);
-    STM_X_STORE(buf_store_row4<kXSc1>(T.wsb, rowb_off(G, T, 0, T.i, K1.fb, true), 0, bottom));
+    const PK K1b = kt_fetch<1>(Kt, L);
+    const bool main_diag = !K1b.restart1;
+    C.c1 = sel_row(K1b.carry_first, Xf[1], Xf[0]);
+    const Row<4> bottom = sel_row(K1b.carry_first && !main_diag, Xf[0], Xf[1]);
+    STM_X_STORE(buf_store_row4<kXSc1>(T.wsb, rowb_off(G, T, 0, T.i, K1b.fb, true), 0, bottom));
   }
   // The next tile's cost rows and its first entries.
   auto prefetch_next = [&] {
     prefetch_cost(N.cost, G, Tn, image, L);
-    N.e0i = buf_load_row4<0>(Tn.wsb, fwd_ie_off(G, Tn, 0, K0.ie[0]), 0);
-    N.e1t = buf_load_row4<kXSc1>(Tn.wsb, have_next ? rowb_off(G, Tn, 0, Tn.i - 1, K1.ft, false) : kNowhere, 0);
-    N.e1i[0] = buf_load_row4<0>(Tn.wsb, fwd_ie_off(G, Tn, 3, K1.ie[0]), 0);
-    N.e1i[1] = buf_load_row4<0>(Tn.wsb, fwd_ie_off(G, Tn, 3, K1.ie[1]), 0);
+    const PK K0n = kt_fetch<0>(Kt, L), K1n = kt_fetch<1>(Kt, L);
+    N.e0i = buf_load_row4<0>(Tn.wsb, fwd_ie_off(G, Tn, 0, K0n.ie[0]), 0);
+    N.e1t = buf_load_row4<kXSc1>(Tn.wsb, have_next ? rowb_off(G, Tn, 0, Tn.i - 1, K1n.ft, false) : kNowhere, 0);
+    N.e1i[0] = buf_load_row4<0>(Tn.wsb, fwd_ie_off(G, Tn, 3, K1n.ie[0]), 0);
+    N.e1i[1] = buf_load_row4<0>(Tn.wsb, fwd_ie_off(G, Tn, 3, K1n.ie[1]), 0);
   };
   if (STM_SKEW_FWD_PREFETCH_AT == 1) prefetch_next();
   if (STM_SKEW_FWD_ENTRIES_AT == 1) load_e3();
   // ---- pair 2: down-right / up-left
   Ef[0] = e2t; Ef[1] = C.c2a; Ef[2] = C.c2b;
-  fwd_pair_w<2, FINAL, GEN>(w, K2, Ef, Ei2, Xf, cls2, sp, G, T, P.true_paths, Ct, St, pen2, X, L, [] { lds_barrier(); });
+  fwd_pair_w<2, FINAL, GEN>(w, kt_fetch<2>(Kt, L), Ef, Ei2, Xf, cls2, sp, G, T, P.true_paths, Ct, St, pen2, X, L, [&] { STM_SK_STAMP(8); lds_barrier(); STM_SK_STAMP(9); });
+  STM_SK_STAMP(10);
   C.c2a = Xf[0];
   C.c2b = Xf[1];  // (wave 3 has no third piece: unused there)
   // (one unconditional store: a store under a condition is a branch, behind which the compiler
   // can no longer count the accesses in flight -- DESIGN.md 4.1d)
-  STM_X_STORE(buf_store_row4<kXSc1>(T.wsb, rowb_off(G, T, 1, T.i, K2.fb, true), 0, sel_row(nb_of(2, w) < kT, Xf[2], Xf[1])));
+  STM_X_STORE(buf_store_row4<kXSc1>(T.wsb, rowb_off(G, T, 1, T.i, kt_fetch<2>(Kt, L).fb, true), 0, sel_row(nb_of(2, w) < kT, Xf[2], Xf[1])));
   if (STM_SKEW_FWD_PREFETCH_AT == 2) prefetch_next();
   // ---- pair 3: down-left / up-right
   Ef[0] = e3t; Ef[1] = e3t; Ef[2] = e3t;
-  fwd_pair_w<3, FINAL, GEN>(w, K3, Ef, Ei3, Xf, cls3, sp, G, T, P.true_paths, Ct, St, pen3, X, L, [] { lds_barrier(); });
-  STM_X_STORE(buf_store_row4<kXSc1>(T.wsb, rowb_off(G, T, 2, T.i, K3.fb, true), 0, Xf[0]));
+  fwd_pair_w<3, FINAL, GEN>(w, kt_fetch<3>(Kt, L), Ef, Ei3, Xf, cls3, sp, G, T, P.true_paths, Ct, St, pen3, X, L, [&] { STM_SK_STAMP(11); lds_barrier(); STM_SK_STAMP(12); });
+  STM_SK_STAMP(13);
+  STM_X_STORE(buf_store_row4<kXSc1>(T.wsb, rowb_off(G, T, 2, T.i, kt_fetch<3>(Kt, L).fb, true), 0, Xf[0]));
 }
 
 __device__ __forceinline__ void make_tile(TileCtx &T, const SkewGeom &G, int i, int j) {
@@ -751,6 +834,7 @@ __global__ __launch_bounds__(kThreads, kD == 128 ? 2 : 1) void sgm_skew_fwd_kern
   __shared__ __attribute__((aligned(16))) float Ct[kT * kT * kD];
   __shared__ __attribute__((aligned(16))) float St[kT * kT * st_stride(kD)];
   __shared__ float Ip[kIpN];
+  __shared__ __attribute__((aligned(16))) unsigned Kt[kKtWords];
   __shared__ int s_unit;
   const SkewGeom &G = P.G;
   const int lane = threadIdx.x & 63;
@@ -758,8 +842,7 @@ __global__ __launch_bounds__(kThreads, kD == 128 ? 2 : 1) void sgm_skew_fwd_kern
   L.init();
   Ctx X;
   ctx_init(X, P.p1, L, P.dlim);
-  PK K0, K1, K2m, K3;
-  pk_init<0>(K0, L); pk_init<1>(K1, L); pk_init<2>(K2m, L); pk_init<3>(K3, L);
+  kt_fill<0>(Kt, L); kt_fill<1>(Kt, L); kt_fill<2>(Kt, L); kt_fill<3>(Kt, L);  // (read behind the loop's first barrier)
   unsigned *status = reinterpret_cast<unsigned *>(ws);
   unsigned *prog = reinterpret_cast<unsigned *>(ws + G.prog_off);
   const size_t npix = (size_t)G.H * G.W;
@@ -789,13 +872,20 @@ __global__ __launch_bounds__(kThreads, kD == 128 ? 2 : 1) void sgm_skew_fwd_kern
     if (L.w == 0 && i > 0) wait_progress(prog_above, (unsigned)progress_needed(G, 0), seen, status, dead);
     __syncthreads();
     prefetch_cost(N.cost, G, T, image, L);
-    N.e0i = buf_load_row4<0>(T.wsb, fwd_ie_off(G, T, 0, K0.ie[0]), 0);
-    N.e1t = buf_load_row4<kXSc1>(T.wsb, rowb_off(G, T, 0, i - 1, K1.ft, false), 0);
-    N.e1i[0] = buf_load_row4<0>(T.wsb, fwd_ie_off(G, T, 3, K1.ie[0]), 0);
-    N.e1i[1] = buf_load_row4<0>(T.wsb, fwd_ie_off(G, T, 3, K1.ie[1]), 0);
+    {
+      const PK K0 = kt_fetch<0>(Kt, L), K1 = kt_fetch<1>(Kt, L);
+      N.e0i = buf_load_row4<0>(T.wsb, fwd_ie_off(G, T, 0, K0.ie[0]), 0);
+      N.e1t = buf_load_row4<kXSc1>(T.wsb, rowb_off(G, T, 0, i - 1, K1.ft, false), 0);
+      N.e1i[0] = buf_load_row4<0>(T.wsb, fwd_ie_off(G, T, 3, K1.ie[0]), 0);
+      N.e1i[1] = buf_load_row4<0>(T.wsb, fwd_ie_off(G, T, 3, K1.ie[1]), 0);
+    }
     C.c0 = N.e0i; C.c1 = N.e0i; C.c2a = N.e0i; C.c2b = N.e0i;  // (any defined value: tile 0's paths begin in it)
     for (int j = 0; j < G.nTC; ++j) {
       make_tile(T, G, i, j);
+#ifdef STM_SKEW_STAMPS
+      T.stamp = P.stamps && b == 0 && i == P.stamp_band && j < 64;
+#endif
+      STM_SK_STAMP(0);
       const bool have_next = j + 1 < G.nTC;
       make_tile(Tn, G, i, have_next ? j + 1 : j);
       stage_cost(N.cost, Ct, Ip, L);
@@ -809,29 +899,22 @@ __global__ __launch_bounds__(kThreads, kD == 128 ? 2 : 1) void sgm_skew_fwd_kern
         seen = ahead > seen ? ahead : seen;
         wait_progress(prog_above, (unsigned)progress_needed(G, j), seen, status, dead);
       }
+      STM_SK_STAMP(1);
       lds_barrier();
       if (L.w == 0 && i > 0) ahead = poll_counter(prog_above);  // (looked at at the top of the next tile)
       // (the band's own progress -- tiles < j are complete -- is published behind pair 1's barrier,
       // in front of which every wave drains its stores: by then the previous tile's last stores
       // have had a pair's time, a drain at the top of the tile would wait for them)
       unsigned *publish = j > 0 ? prog_mine : nullptr;
-      // Pair 2's per-lane constants are read from (scratch) MEMORY, through a pointer the compiler
-      // cannot see through and that is new every tile (else it hoists the loads out of the loop,
-      // back into registers): the kernel runs at the 256-register limit, and with these eight in
-      // registers hipcc spills ~100 others around the tile loop (24.9 against 21.7 ms per 256 Teddy
-      // pairs; all four pairs' constants in memory: 28.7 -- the scratch loads of the other pairs'
-      // slot addresses are then on the chains' way; the reverse pass, which has registers to
-      // spare, keeps them all in registers).
-      const PK *k2p = &K2m;
-      asm volatile("" : "+v"(k2p));
-      const PK &K2 = *k2p;
-      if (T.gen) fwd_tile<FINAL, true>(P, T, Tn, have_next, K0, K1, K2, K3, C, N, image, Ct, St, Ip, X, L, lane, publish);
-      else fwd_tile<FINAL, false>(P, T, Tn, have_next, K0, K1, K2, K3, C, N, image, Ct, St, Ip, X, L, lane, publish);
+      if (T.gen) fwd_tile<FINAL, true>(P, T, Tn, have_next, Kt, C, N, image, Ct, St, Ip, X, L, lane, publish);
+      else fwd_tile<FINAL, false>(P, T, Tn, have_next, Kt, C, N, image, Ct, St, Ip, X, L, lane, publish);
       lds_barrier();
+      STM_SK_STAMP(14);
       if constexpr (FINAL != 0) {
         const bool sp = count_class(2, G, i, j, P.true_paths) == 3 || count_class(3, G, i, j, P.true_paths) == 3;
         skew_wta(St, L.w, lane, G, T.x0, T.y0, disp, sp, P.true_paths);
       }
+      STM_SK_STAMP(15);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1024,6 +1107,9 @@ int skew_launch_d256
      float p2, int dlim, int true_paths, hipStream_t stream, int final_mode, int cus) {
   SkewArgs A;
   A.G = G; A.p1 = p1; A.p2 = p2; A.dlim = dlim; A.true_paths = true_paths;
+#ifdef STM_SKEW_STAMPS
+  A.stamps = g_skew_stamps; A.stamp_band = g_skew_stamp_band;
+#endif
   const long long units = (long long)G.batch * G.nTR;
   {
     const long long wgs = (long long)cus * (kD == 128 ? STM_SKEW_REV_OCC : 1);
@@ -1045,3 +1131,9 @@ int skew_launch_d256
 
 }  // namespace stm
 
+#if defined(STM_SKEW_STAMPS) && STM_SKEW_D == 128
+extern "C" void stm_debug_set_skew_stamps(void *p, int band) {
+  stm::g_skew_stamps = static_cast<unsigned long long *>(p);
+  stm::g_skew_stamp_band = band;
+}
+#endif
