@@ -20,6 +20,9 @@ using std::integral_constant;
 #ifndef STM_SKEW_FWD_PREFETCH_AT
 #define STM_SKEW_FWD_PREFETCH_AT 2  // the next tile's cost rows are requested behind pair 1 / pair 2
 #endif
+#ifndef STM_SKEW_FWD_SPREAD
+#define STM_SKEW_FWD_SPREAD 0
+#endif
 #ifndef STM_SKEW_POLL_SLEEP
 #define STM_SKEW_POLL_SLEEP 16  // s_sleep between two polls of a progress counter (units of 64 clocks)
 #endif
@@ -219,6 +222,28 @@ __device__ __forceinline__ void prefetch_cost(Pre &P, const SkewGeom &G, const T
   const int y = imin_(imax_(T.y0 + rr, 0), G.H - 1), x = imin_(imax_(T.x0 + uu - rr, 0), G.W - 1);
   P.ipre = image[y * G.W + x];
 }
+// ... one row of it at a time (the forward pass spreads the next tile's requests over the steps of a
+// pair: thirteen vector-memory instructions issued back to back by all four waves at once wait
+// for the CU's one address unit, and a wave that cannot issue does nothing else either).
+template <int U>
+__device__ __forceinline__ void prefetch_cost_row(Pre &P, const SkewGeom &G, const TileCtx &T, const LaneId &L) {
+  const int r = L.row;
+  unsigned off;
+  if (!T.gen) {
+    off = ((unsigned)((T.y0 + r) * G.W + T.x0 - r) * (unsigned)kD + (unsigned)L.d0) * 4u + (unsigned)(U * kRowBytes);
+  } else {
+    const int y = imin_(T.y0 + r, G.H - 1);
+    const int x = imin_(imax_(T.x0 + U - r, 0), G.W - 1);
+    off = ((unsigned)(y * G.W + x) * (unsigned)kD + (unsigned)L.d0) * 4u;
+  }
+  P.cpre[U] = buf_load_row4<0>(T.cost, off, 0);
+}
+__device__ __forceinline__ void prefetch_patch(Pre &P, const SkewGeom &G, const TileCtx &T, const float *image) {
+  const int e = imin_((int)threadIdx.x, kIpN - 1);
+  const int rr = e / kIpW - 1, uu = e % kIpW - 2;
+  const int y = imin_(imax_(T.y0 + rr, 0), G.H - 1), x = imin_(imax_(T.x0 + uu - rr, 0), G.W - 1);
+  P.ipre = image[y * G.W + x];
+}
 __device__ __forceinline__ void stage_cost(const Pre &P, float *Ct, float *Ip, const LaneId &L) {
   const int r = L.row;
 #pragma unroll
@@ -289,11 +314,13 @@ __device__ __forceinline__ Row<4> sel_row(bool c, const Row<4> &a, const Row<4> 
 //   Ef / Ei   entry states per piece (slot order); Xf: the forward chain's state after each piece.
 //   cls       count class of the tile for this pair (skew::count_class).
 // =====================================================================================
-template <int PHASE, int NA, int NB, int FINAL, bool GEN, typename Between>
+template <int PHASE, int NA, int NB, int FINAL, bool GEN, typename Hook>
 __device__ __forceinline__ void fwd_pair(const PK &K, const Row<4> (&Ef)[3], const Row<4> (&Ei)[3], Row<4> (&Xf)[3],
                                          int cls, bool sp, const SkewGeom &G, const TileCtx &T, int true_paths,
                                          const float *Ct, float *St, float pen, Ctx &X, const LaneId &L,
-                                         Between between) {
+                                         Hook hook) {
+  // hook(s): called in front of step s; the one of step kT / 2 holds the workgroup's barrier behind
+  // which the sum tile may be read and updated.
   constexpr int pstep = tile_pstep(PHASE);
   constexpr int NP = NB < kT ? 3 : (NA < kT ? 2 : 1);
   Ctx XI = X;
@@ -398,8 +425,8 @@ __device__ __forceinline__ void fwd_pair(const PK &K, const Row<4> (&Ef)[3], con
         cfn = h2_lds_row(Ct, addr(integral_constant<int, s + 1>()));
         cin = h2_lds_row(Ct, addr(integral_constant<int, r - 1>()));
       }
+      hook(s_);
       if constexpr (s == kT / 2) {
-        between();
         sa = sum_of(integral_constant<int, s>());
         sb = sum_of(integral_constant<int, r>());
       }
@@ -430,10 +457,11 @@ __device__ __forceinline__ void fwd_pair(const PK &K, const Row<4> (&Ef)[3], con
     both(integral_constant<int, 6>()); both(integral_constant<int, 7>());
   } else {
     // No inverse pass counts anywhere in this tile (Q6): the forward chain alone.
-    between();
+    hook(integral_constant<int, kT / 2>());
     Row<4> sa = sum_of(integral_constant<int, 0>());
     auto fstep = [&](auto s_) {
       constexpr int s = decltype(s_)::value;
+      if constexpr (s != kT / 2) hook(s_);
       if constexpr (NA < kT && s == NA) pf = PHASE == 1 ? sel_row(K.restart1, Ef[1], pf) : Ef[1];
       if constexpr (NB < kT && s == NB) pf = Ef[2];
       const Row<4> c = h2_lds_row(Ct, addr(s_));
@@ -453,13 +481,13 @@ __device__ __forceinline__ void fwd_pair(const PK &K, const Row<4> (&Ef)[3], con
   }
 }
 
-template <int PHASE, int FINAL, bool GEN, typename Between>
+template <int PHASE, int FINAL, bool GEN, typename Hook>
 __device__ __forceinline__ void fwd_pair_w(int w, const PK &K, const Row<4> (&Ef)[3], const Row<4> (&Ei)[3],
                                            Row<4> (&Xf)[3], int cls, bool sp, const SkewGeom &G, const TileCtx &T,
                                            int true_paths, const float *Ct, float *St, float pen, Ctx &X,
-                                           const LaneId &L, Between between) {
+                                           const LaneId &L, Hook hook) {
 #define STM_FWD_PAIR(NA, NB) \
-  fwd_pair<PHASE, NA, NB, FINAL, GEN>(K, Ef, Ei, Xf, cls, sp, G, T, true_paths, Ct, St, pen, X, L, between)
+  fwd_pair<PHASE, NA, NB, FINAL, GEN>(K, Ef, Ei, Xf, cls, sp, G, T, true_paths, Ct, St, pen, X, L, hook)
   if constexpr (PHASE == 0 || PHASE == 3) {
     STM_FWD_PAIR(kT, kT);
   } else if constexpr (PHASE == 1 && kD == 128) {
@@ -607,28 +635,33 @@ __device__ __forceinline__ void skew_wta(const float *St, int wave, int lane, co
                                          int32_t *__restrict__ disp, bool sp, int true_paths) {
   constexpr int LP = kWaves, NJ = kD / (LP * 4);  // lanes per pixel: a wave takes 64 / kWaves pixels
   typedef float v4f __attribute__((ext_vector_type(4)));
+  // Lane r of a pixel's LP lanes reads the 16-byte chunks M r + j % M + 16 (j / M), M = 16 / LP: the
+  // sixteen lanes of a quarter-wave (16 / LP pixels, a pixel's row 4 banks further than its
+  // predecessor's) then touch sixteen different bank groups (chunks r + LP j: up to four lanes on one).
+  constexpr int M = 16 / LP;
   const int pix = wave * (64 / LP) + lane / LP, r = lane % LP;
-  const float *p = St + pix * st_stride(kD) + r * 4;
+  const float *p = St + pix * st_stride(kD) + r * (M * 4);
   float best = __builtin_inff();
   int idxk = 0;
   bool nan0 = false;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const v4f q = *reinterpret_cast<const v4f *>(p + j * LP * 4);
+    const int cj = (j % M) + 16 * (j / M);  // the chunk, less the lane's M r
+    const v4f q = *reinterpret_cast<const v4f *>(p + cj * 4);
     const float v[4] = {q.x, q.y, q.z, q.w};
     if (j == 0) nan0 = r == 0 && v[0] != v[0];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const bool lt = v[e] < best;
       best = lt ? v[e] : best;
-      idxk = lt ? j * LP * 4 + e : idxk;
+      idxk = lt ? cj * 4 + e : idxk;
     }
   }
   float m = best;
   m = vmin_f32(m, dpp_f32<0xb1>(m, m));
   m = vmin_f32(m, dpp_f32<0x4e>(m, m));
   if (LP == 8) m = vmin_f32(m, dpp_f32<0x141>(m, m));  // row_half_mirror
-  int k = best == m ? idxk + r * 4 : 0x7fffffff;
+  int k = best == m ? idxk + r * (M * 4) : 0x7fffffff;
   k = nan0 ? 0 : k;
   int t;
   t = dpp_i32<0xb1>(k, k); k = t < k ? t : k;
@@ -763,7 +796,7 @@ __device__ __forceinline__ void fwd_tile(const SkewArgs &P, const TileCtx &T, co
   Ef[0] = C.c0; Ef[1] = C.c0; Ef[2] = C.c0;
   Ei[0] = N.e0i; Ei[1] = N.e0i; Ei[2] = N.e0i;
   STM_SK_STAMP(2);
-  fwd_pair_w<0, FINAL, GEN>(w, kt_fetch<0>(Kt, L), Ef, Ei, Xf, 1, false, G, T, P.true_paths, Ct, St, pen0, X, L, [] {});
+  fwd_pair_w<0, FINAL, GEN>(w, kt_fetch<0>(Kt, L), Ef, Ei, Xf, 1, false, G, T, P.true_paths, Ct, St, pen0, X, L, [](auto) {});
   STM_SK_STAMP(3);
   C.c0 = Xf[0];
   if (STM_SKEW_FWD_ENTRIES_AT == 1) load_e2();
@@ -772,7 +805,8 @@ __device__ __forceinline__ void fwd_tile(const SkewArgs &P, const TileCtx &T, co
   Ef[0] = sel_row(K1.carry_first, C.c1, N.e1t);
   Ef[1] = sel_row(K1.carry_first, N.e1t, C.c1);
   Ei[0] = N.e1i[0]; Ei[1] = N.e1i[1]; Ei[2] = N.e1i[1];
-  fwd_pair_w<1, FINAL, GEN>(w, K1, Ef, Ei, Xf, 1, false, G, T, P.true_paths, Ct, St, pen1, X, L, [&] {
+  fwd_pair_w<1, FINAL, GEN>(w, K1, Ef, Ei, Xf, 1, false, G, T, P.true_paths, Ct, St, pen1, X, L, [&](auto s_) {
+    if constexpr (decltype(s_)::value != kT / 2) return;
     STM_SK_STAMP(4);
 #ifndef STM_SKEW_X_NODRAIN
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores of the previous tile have landed
@@ -791,29 +825,51 @@ __device__ __forceinline__ void fwd_tile(const SkewArgs &P, const TileCtx &T, co
     STM_X_STORE(buf_store_row4<kXSc1>(T.wsb, rowb_off(G, T, 0, T.i, K1b.fb, true), 0, bottom));
   }
   // The next tile's cost rows and its first entries.
+  // STM_SKEW_FWD_SPREAD: one request (a cost row, an entry) in front of each step -- 1: of pair 3;
+  // 2: of pair 2's second and pair 3's first half; 0: all of them at once (STM_SKEW_FWD_PREFETCH_AT).
+  auto prefetch_entry = [&](auto k_) {
+    constexpr int k = decltype(k_)::value;
+    if constexpr (k == 0) N.e0i = buf_load_row4<0>(Tn.wsb, fwd_ie_off(G, Tn, 0, kt_fetch<0>(Kt, L).ie[0]), 0);
+    if constexpr (k == 1) N.e1t = buf_load_row4<kXSc1>(Tn.wsb, have_next ? rowb_off(G, Tn, 0, Tn.i - 1, kt_fetch<1>(Kt, L).ft, false) : kNowhere, 0);
+    if constexpr (k == 2) N.e1i[0] = buf_load_row4<0>(Tn.wsb, fwd_ie_off(G, Tn, 3, kt_fetch<1>(Kt, L).ie[0]), 0);
+    if constexpr (k == 3) N.e1i[1] = buf_load_row4<0>(Tn.wsb, fwd_ie_off(G, Tn, 3, kt_fetch<1>(Kt, L).ie[1]), 0);
+  };
   auto prefetch_next = [&] {
     prefetch_cost(N.cost, G, Tn, image, L);
-    const PK K0n = kt_fetch<0>(Kt, L), K1n = kt_fetch<1>(Kt, L);
-    N.e0i = buf_load_row4<0>(Tn.wsb, fwd_ie_off(G, Tn, 0, K0n.ie[0]), 0);
-    N.e1t = buf_load_row4<kXSc1>(Tn.wsb, have_next ? rowb_off(G, Tn, 0, Tn.i - 1, K1n.ft, false) : kNowhere, 0);
-    N.e1i[0] = buf_load_row4<0>(Tn.wsb, fwd_ie_off(G, Tn, 3, K1n.ie[0]), 0);
-    N.e1i[1] = buf_load_row4<0>(Tn.wsb, fwd_ie_off(G, Tn, 3, K1n.ie[1]), 0);
+    prefetch_entry(integral_constant<int, 0>()); prefetch_entry(integral_constant<int, 1>());
+    prefetch_entry(integral_constant<int, 2>()); prefetch_entry(integral_constant<int, 3>());
   };
-  if (STM_SKEW_FWD_PREFETCH_AT == 1) prefetch_next();
+  // (k: 0..7 the cost rows with the four entries beside rows 0..3, the intensities beside row 4)
+  auto prefetch_part = [&](auto k_) {
+    constexpr int k = decltype(k_)::value;
+    prefetch_cost_row<k>(N.cost, G, Tn, L);
+    if constexpr (k < 4) prefetch_entry(k_);
+    if constexpr (k == 4) prefetch_patch(N.cost, G, Tn, image);
+  };
+  if (STM_SKEW_FWD_SPREAD == 0 && STM_SKEW_FWD_PREFETCH_AT == 1) prefetch_next();
   if (STM_SKEW_FWD_ENTRIES_AT == 1) load_e3();
   // ---- pair 2: down-right / up-left
   Ef[0] = e2t; Ef[1] = C.c2a; Ef[2] = C.c2b;
-  fwd_pair_w<2, FINAL, GEN>(w, kt_fetch<2>(Kt, L), Ef, Ei2, Xf, cls2, sp, G, T, P.true_paths, Ct, St, pen2, X, L, [&] { STM_SK_STAMP(8); lds_barrier(); STM_SK_STAMP(9); });
+  fwd_pair_w<2, FINAL, GEN>(w, kt_fetch<2>(Kt, L), Ef, Ei2, Xf, cls2, sp, G, T, P.true_paths, Ct, St, pen2, X, L, [&](auto s_) {
+    constexpr int s = decltype(s_)::value;
+    if constexpr (s == kT / 2) { STM_SK_STAMP(8); lds_barrier(); STM_SK_STAMP(9); }
+    if constexpr (STM_SKEW_FWD_SPREAD == 2 && s >= kT / 2) prefetch_part(integral_constant<int, s - kT / 2>());
+  });
   STM_SK_STAMP(10);
   C.c2a = Xf[0];
   C.c2b = Xf[1];  // (wave 3 has no third piece: unused there)
   // (one unconditional store: a store under a condition is a branch, behind which the compiler
   // can no longer count the accesses in flight -- DESIGN.md 4.1d)
   STM_X_STORE(buf_store_row4<kXSc1>(T.wsb, rowb_off(G, T, 1, T.i, kt_fetch<2>(Kt, L).fb, true), 0, sel_row(nb_of(2, w) < kT, Xf[2], Xf[1])));
-  if (STM_SKEW_FWD_PREFETCH_AT == 2) prefetch_next();
+  if (STM_SKEW_FWD_SPREAD == 0 && STM_SKEW_FWD_PREFETCH_AT == 2) prefetch_next();
   // ---- pair 3: down-left / up-right
   Ef[0] = e3t; Ef[1] = e3t; Ef[2] = e3t;
-  fwd_pair_w<3, FINAL, GEN>(w, kt_fetch<3>(Kt, L), Ef, Ei3, Xf, cls3, sp, G, T, P.true_paths, Ct, St, pen3, X, L, [&] { STM_SK_STAMP(11); lds_barrier(); STM_SK_STAMP(12); });
+  fwd_pair_w<3, FINAL, GEN>(w, kt_fetch<3>(Kt, L), Ef, Ei3, Xf, cls3, sp, G, T, P.true_paths, Ct, St, pen3, X, L, [&](auto s_) {
+    constexpr int s = decltype(s_)::value;
+    if constexpr (s == kT / 2) { STM_SK_STAMP(11); lds_barrier(); STM_SK_STAMP(12); }
+    if constexpr (STM_SKEW_FWD_SPREAD == 1) prefetch_part(s_);
+    if constexpr (STM_SKEW_FWD_SPREAD == 2 && s < kT / 2) prefetch_part(integral_constant<int, s + kT / 2>());
+  });
   STM_SK_STAMP(13);
   STM_X_STORE(buf_store_row4<kXSc1>(T.wsb, rowb_off(G, T, 2, T.i, kt_fetch<3>(Kt, L).fb, true), 0, Xf[0]));
 }
@@ -1131,8 +1187,12 @@ int skew_launch_d256
 
 }  // namespace stm
 
-#if defined(STM_SKEW_STAMPS) && STM_SKEW_D == 128
-extern "C" void stm_debug_set_skew_stamps(void *p, int band) {
+#if defined(STM_SKEW_STAMPS)
+#if STM_SKEW_D == 128
+extern "C" void stm_debug_set_skew_stamps_d128(void *p, int band) {
+#else
+extern "C" void stm_debug_set_skew_stamps_d256(void *p, int band) {
+#endif
   stm::g_skew_stamps = static_cast<unsigned long long *>(p);
   stm::g_skew_stamp_band = band;
 }

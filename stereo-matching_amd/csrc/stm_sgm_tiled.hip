@@ -114,20 +114,20 @@ SgmForm sgm_form(int H, int W, int D, int batch, int flags) {
   // bands (a band starts three tiles behind the one it depends on): ~5 ms for a Teddy-sized image
   // whatever the batch, so it needs several units (image, band) per workgroup to amortise that.
   // Measured on MI355X (tools/gpu_jobs/forms_sweep.sh, Teddy 375 x 450 x 128, fused, ms per pair):
-  //   B =                      16     32     64     128    256
-  //   tiles behind walks       0.233  0.228  0.234  0.218
-  //   tiles behind sweeps      0.266  0.191  0.176  0.163  0.154
-  //   skewed tiles             0.360  0.201  0.148  0.132  0.127
-  //   1080p, D = 256           8      16     32          (tools/sgm_forms.py)
-  //   tiles behind sweeps      3.74   3.65   3.59
-  //   skewed tiles             3.87   3.41   3.10
+  //   B =                      16     24     32     48     64     128    256
+  //   tiles behind walks       0.233         0.228         0.234  0.218
+  //   tiles behind sweeps      0.266  0.216  0.189  0.182  0.176  0.163  0.154
+  //   skewed tiles             0.248  0.181  0.144  0.126  @64    @128   0.107
+  //   1080p, D = 256           4      8      16          (tools/sgm_forms.py)
+  //   tiles behind sweeps      3.88   3.63   3.64
+  //   skewed tiles             4.44   3.38   2.90
   // (D = 256: one workgroup per CU, so eight 1080p pairs are 1,080 bands for 256 workgroups -- five
   // rounds for 4.2 rounds of work, and a band is a serial chain of 241 tiles that no finer unit
   // shortens: band segments were built and measured, 40.6 against 30.9 ms)
   if (!(flags & (STM_SGM_PAIRED | STM_SGM_TILED | STM_SGM_WALKS)) && skew_covers(H, W, D, batch, flags)) {
     const int cus = device_cus();
     const long long bands = (long long)batch * ((H + kT - 1) / kT), wgs = (long long)cus * (D == 128 ? 2 : 1);
-    if (cus > 0 && bands >= (D == 128 ? 4 : 6) * wgs && W >= 64) return kSgmSkew;
+    if (cus > 0 && bands >= (D == 128 ? 2 : 4) * wgs && W >= 64) return kSgmSkew;
   }
   if (!shape_ok(H, W, D, batch, flags)) return kSgmPaired;
   TiledGeom G;

@@ -124,7 +124,8 @@ def test_auto_form_takes_skewed_tiles_for_large_d128_batches(device, oracle):
     assert lib.stm_sgm_form(375, 450, 128, 256, _native.STM_SGM_FORMS["paired"]) == _native.STM_SGM_FORM_PAIRED
     assert lib.stm_sgm_form(375, 450, 128, 256, _native.STM_SGM_ACCUMULATE) != _native.STM_SGM_FORM_SKEW
     assert lib.stm_sgm_form(375, 450, 64, 256, _native.STM_SGM_FORMS["skew"]) != _native.STM_SGM_FORM_SKEW
-    assert lib.stm_sgm_form(1080, 1920, 256, 8, 0) == _native.STM_SGM_FORM_SWEEPS
+    assert lib.stm_sgm_form(1080, 1920, 256, 8, 0) == _native.STM_SGM_FORM_SKEW
+    assert lib.stm_sgm_form(1080, 1920, 256, 4, 0) == _native.STM_SGM_FORM_SWEEPS
     assert lib.stm_sgm_form(1080, 1920, 256, 16, 0) == _native.STM_SGM_FORM_SKEW
     assert lib.stm_sgm_form(1080, 1920, 256, 2, _native.STM_SGM_FORMS["skew"]) == _native.STM_SGM_FORM_SKEW
     assert lib.stm_sgm_form(40, 90, 128, 2, _native.STM_SGM_FORMS["skew"]) == _native.STM_SGM_FORM_SKEW

@@ -28,7 +28,8 @@ def main():
     for name, (restype, argtypes) in _native.PROTOTYPES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = restype, argtypes
-    lib.stm_debug_set_skew_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    setter = lib.stm_debug_set_skew_stamps_d128 if D == 128 else lib.stm_debug_set_skew_stamps_d256
+    setter.argtypes = [ctypes.c_void_p, ctypes.c_int]
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(1)
     cost = (torch.rand((B, H, W, D), generator=g) * 50).to(dev)
@@ -40,7 +41,7 @@ def main():
     ws = torch.empty(n, dtype=torch.uint8, device=dev)
     nw = 4 if D == 128 else 8
     stamps = torch.zeros((64, nw, 16), dtype=torch.int64, device=dev)
-    lib.stm_debug_set_skew_stamps(stamps.data_ptr(), band)
+    setter(stamps.data_ptr(), band)
     s = torch.cuda.current_stream().cuda_stream
     for _ in range(2):
         rc = lib.stm_sgm_wta_f32(cost.data_ptr(), image.data_ptr(), scratch.data_ptr(), disp.data_ptr(),
