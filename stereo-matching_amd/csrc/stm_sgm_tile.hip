@@ -176,7 +176,7 @@ __global__ __launch_bounds__(2 * kT * 64, VPL >= 4 ? 4 : 8) void sgm_tile_kernel
       Entries<VPL, 2> E2;
       load_entries<VPL, 2>(E2, g2, border_base(ws, G, b), G, x0, y0, d0);
       tile_pair<VPL, 0, FINAL>(tile_geom(0, w, tw, th), E0now, full, Ct, St, Ip, P, x0, y0, out, disp, X, lane,
-                               [] {}, rows ? &carry : nullptr);
+                               [] {}, &carry);  // (unconditionally: a pointer that may be null keeps `carry` in scratch memory)
       have_carry = rows && tw == kT && !last_of_unit;
       // A segment's last tile leaves its rows' states for the segment on its right.
       const bool hand_over = last_of_unit && cur_t.tend < G.nTC;

@@ -16,6 +16,36 @@ __device__ __forceinline__ void h2_load_entries(Row<4> (&E)[4], const H2Pair &K,
   }
 }
 
+// The lines' constants (H2Pair: the same for the 32 lanes of a half-wave) live in LDS, one row of
+// eight words per (pair, half-wave), and are fetched where they are used: the kernel runs at the
+// 256-register limit, and what hipcc spills around the tile loop it reloads from scratch memory
+// with an s_waitcnt vmcnt(0) -- behind the next tile's cost rows and entry states, requested
+// ahead on purpose, i.e. a memory round trip per reload (as in the skewed-tile form's forward
+// pass, stm_sgm_skew_body.h).  An LDS read waits for LDS reads only.
+constexpr int kKtN = 8;
+template <int PHASE>
+__device__ __forceinline__ void h2_kt_fill(int *Kt, const TiledGeom &G, int w, int half, int hl) {
+  H2Pair K;
+  h2_pair_init<PHASE>(K, G, w, half);
+  if (hl == 0) {
+    int *row = Kt + ((PHASE * 4 + w) * 2 + half) * kKtN;
+    row[0] = K.pix0; row[1] = K.pix1; row[2] = K.restart ? 1 : 0; row[3] = 0;
+    row[4] = K.eoff[0]; row[5] = K.eoff[1]; row[6] = K.eoff[2]; row[7] = K.eoff[3];
+  }
+}
+// (every fetch is a new one: nothing of an earlier fetch stays in registers for it; what the
+// caller does not use is not loaded)
+template <int PHASE>
+__device__ __forceinline__ H2Pair h2_kt_fetch(const int *Kt, int w, int half) {
+  int o = ((PHASE * 4 + w) * 2 + half) * kKtN;
+  asm volatile("" : "+v"(o));
+  const int *row = Kt + o;
+  H2Pair K;
+  K.pix0 = row[0]; K.pix1 = row[1]; K.restart = row[2] != 0;
+  K.eoff[0] = row[4]; K.eoff[1] = row[5]; K.eoff[2] = row[6]; K.eoff[3] = row[7];
+  return K;
+}
+
 // Penalties of the lane's line: lane i of every 16-lane row holds the one of slot i & 7 on
 // the F chain (i < 8: the step from its predecessor) or the I chain (from its successor).
 template <int PHASE>
@@ -249,6 +279,7 @@ __global__ __launch_bounds__(4 * 64, 2) void sgm_tile_h2_kernel(const float *__r
   __shared__ __attribute__((aligned(16))) float Ct[kT * kT * D];
   __shared__ __attribute__((aligned(16))) float St[kT * kT * st_stride(D)];
   __shared__ float Ip[(kT + 2) * (kT + 2)];
+  __shared__ __attribute__((aligned(16))) int Kt[4 * 4 * 2 * kKtN];
   const TiledGeom &G = P.G;
   const int lane = threadIdx.x & 63;
   const int w = wave_uniform((int)(threadIdx.x >> 6));
@@ -260,11 +291,15 @@ __global__ __launch_bounds__(4 * 64, 2) void sgm_tile_h2_kernel(const float *__r
   X.init(P.p1, hl, P.dlim);
   StepCtx X1;  // the generic forms: one pixel per wave, two values per lane
   X1.init(P.p1, lane * 2, P.dlim, lane == 63 && P.dlim < D);
-  H2Pair K0, K1, K2, K3;
-  h2_pair_init<0>(K0, G, w, half);
-  h2_pair_init<1>(K1, G, w, half);
-  h2_pair_init<2>(K2, G, w, half);
-  h2_pair_init<3>(K3, G, w, half);
+  h2_kt_fill<0>(Kt, G, w, half, hl);
+  h2_kt_fill<1>(Kt, G, w, half, hl);
+  h2_kt_fill<2>(Kt, G, w, half, hl);
+  h2_kt_fill<3>(Kt, G, w, half, hl);
+  __syncthreads();
+#define K0 h2_kt_fetch<0>(Kt, w, half)
+#define K1 h2_kt_fetch<1>(Kt, w, half)
+#define K2 h2_kt_fetch<2>(Kt, w, half)
+#define K3 h2_kt_fetch<3>(Kt, w, half)
   // A workgroup owns whole tile rows and walks them left to right: the rightward state with
   // which a row leaves a tile is the next tile's entry state and stays in registers (between
   // two tiles of this form; otherwise it goes through the column border states, which every
@@ -418,6 +453,10 @@ __global__ __launch_bounds__(4 * 64, 2) void sgm_tile_h2_kernel(const float *__r
     if (!more) break;
     cur_t = next_t;
   }
+#undef K0
+#undef K1
+#undef K2
+#undef K3
 }
 
 
