@@ -362,12 +362,14 @@ struct SlideShape {
 };
 
 // Row samples a strip needs from one image row, in registers: the left row segment
-// L[row][c0-k+i] (i = lane, lane+64) for the v_readlane hand-out and the right row segment
+// L[row][c0-k+16j+i] (i = lane & 15: every 16-lane row holds the same sixteen samples, handed
+// out inside the subtraction by a DPP row broadcast) and the right row segment
 // R[row][c0-k-(d0+63)+i] (i = lane, lane+64, lane+128) that is staged through LDS.
 // Rows outside the image (or not yet part of the band's window) read as zeros on both
 // sides, so they contribute (0-0)^2 = 0 and need no separate code path.
+constexpr int kSlideLJ = (kSlideNV + 15) / 16;  // registers of sixteen left samples
 struct SlideRow {
-  float l0, l1, r0, r1, r2;
+  float l[kSlideLJ], r0, r1, r2;
 };
 
 __device__ __forceinline__ SlideRow slide_fetch(const float *__restrict__ L,
@@ -376,10 +378,11 @@ __device__ __forceinline__ SlideRow slide_fetch(const float *__restrict__ L,
   SlideRow q;
   const float *Lrow = L + (size_t)(live ? row : 0) * W;
   const float *Rrow = R + (size_t)(live ? row : 0) * W;
-  const int lc = c0 - kSlideK + lane;
+  const int lc = c0 - kSlideK + (lane & 15);
   const int rc = c0 - kSlideK - (d0 + 63) + lane;
-  q.l0 = (live && lc >= 0 && lc < W) ? Lrow[lc] : 0.0f;
-  q.l1 = (live && lane < kSlideNV - 64 && lc + 64 >= 0 && lc + 64 < W) ? Lrow[lc + 64] : 0.0f;
+#pragma unroll
+  for (int j = 0; j < kSlideLJ; ++j)
+    q.l[j] = (live && lc + 16 * j >= 0 && lc + 16 * j < W) ? Lrow[lc + 16 * j] : 0.0f;
   q.r0 = (live && rc >= 0 && rc < W) ? Rrow[rc] : 0.0f;
   q.r1 = (live && rc + 64 >= 0 && rc + 64 < W) ? Rrow[rc + 64] : 0.0f;
   q.r2 = (live && lane < kSlideNV + 63 - 128 && rc + 128 >= 0 && rc + 128 < W) ? Rrow[rc + 128] : 0.0f;
@@ -394,6 +397,66 @@ __device__ __forceinline__ void slide_stage(float *lds_row, const SlideRow &q, i
   if (lane < kSlideRW - 128) lds_row[lane + 128] = q.r2;
 }
 
+// Eight differences L[kc] - R[kc - d] at once: the left sample of tap I0 + i is lane I0 + i of every
+// 16-lane row of `l`, broadcast inside the subtraction (v_sub_f32_dpp row_newbcast) -- no
+// v_readlane, no copy of a scalar into a register pair for a packed subtraction (together a
+// third of the kernel's instructions).  The leading s_nop covers a VALU write of `l` just before.
+#define STM_SLIDE_SUB8(I0)                                                                            \
+  asm("s_nop 1\n\t"                                                                                   \
+      "v_sub_f32_dpp %0, %8, %9 row_newbcast:" #I0 "+0 row_mask:0xf bank_mask:0xf\n\t"                 \
+      "v_sub_f32_dpp %1, %8, %10 row_newbcast:" #I0 "+1 row_mask:0xf bank_mask:0xf\n\t"                \
+      "v_sub_f32_dpp %2, %8, %11 row_newbcast:" #I0 "+2 row_mask:0xf bank_mask:0xf\n\t"                \
+      "v_sub_f32_dpp %3, %8, %12 row_newbcast:" #I0 "+3 row_mask:0xf bank_mask:0xf\n\t"                \
+      "v_sub_f32_dpp %4, %8, %13 row_newbcast:" #I0 "+4 row_mask:0xf bank_mask:0xf\n\t"                \
+      "v_sub_f32_dpp %5, %8, %14 row_newbcast:" #I0 "+5 row_mask:0xf bank_mask:0xf\n\t"                \
+      "v_sub_f32_dpp %6, %8, %15 row_newbcast:" #I0 "+6 row_mask:0xf bank_mask:0xf\n\t"                \
+      "v_sub_f32_dpp %7, %8, %16 row_newbcast:" #I0 "+7 row_mask:0xf bank_mask:0xf"                     \
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]) \
+      : "v"(l), "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7]))
+template <int I0>
+__device__ __forceinline__ void slide_sub8(float (&o)[8], float l, const float (&r)[8]) {
+  static_assert(I0 == 0 || I0 == 8, "a register holds sixteen samples");
+  if constexpr (I0 == 0) STM_SLIDE_SUB8(0);
+  else STM_SLIDE_SUB8(8);
+}
+#undef STM_SLIDE_SUB8
+
+// The whole update V = (V + (le - re)^2) - (lx - rx)^2 of eight window columns (interior strips):
+// written out, hipcc packs the multiplications and additions of column pairs and copies every
+// operand into a register pair first -- as many v_mov as arithmetic.
+#define STM_SLIDE_UPD1(N, I)                                                                  \
+  "v_sub_f32_dpp %8, %10, %" #N " row_newbcast:" #I " row_mask:0xf bank_mask:0xf\n\t"         \
+  "v_sub_f32_dpp %9, %11, %" #N "+8 row_newbcast:" #I " row_mask:0xf bank_mask:0xf\n\t"
+template <int I0>
+__device__ __forceinline__ void slide_upd8(float &v0, float &v1, float &v2, float &v3, float &v4, float &v5,
+                                           float &v6, float &v7, float le, float lx, const float (&re)[8],
+                                           const float (&rx)[8]) {
+  static_assert(I0 == 0 || I0 == 8, "a register holds sixteen samples");
+  float t0, t1;
+#define STM_SLIDE_TAP(V, RE, RX, I)                                                          \
+  "v_sub_f32_dpp %8, %10, " RE " row_newbcast:" I " row_mask:0xf bank_mask:0xf\n\t"           \
+  "v_sub_f32_dpp %9, %11, " RX " row_newbcast:" I " row_mask:0xf bank_mask:0xf\n\t"           \
+  "v_mul_f32 %8, %8, %8\n\t"                                                                 \
+  "v_mul_f32 %9, %9, %9\n\t"                                                                 \
+  "v_add_f32 " V ", " V ", %8\n\t"                                                           \
+  "v_sub_f32 " V ", " V ", %9\n\t"
+#define STM_SLIDE_BLOCK(A, B, C, D, E, F, G, H)                                               \
+  asm("s_nop 1\n\t"                                                                          \
+      STM_SLIDE_TAP("%0", "%12", "%20", A) STM_SLIDE_TAP("%1", "%13", "%21", B)              \
+      STM_SLIDE_TAP("%2", "%14", "%22", C) STM_SLIDE_TAP("%3", "%15", "%23", D)              \
+      STM_SLIDE_TAP("%4", "%16", "%24", E) STM_SLIDE_TAP("%5", "%17", "%25", F)              \
+      STM_SLIDE_TAP("%6", "%18", "%26", G) STM_SLIDE_TAP("%7", "%19", "%27", H)              \
+      "s_nop 0"                                                                              \
+      : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "=&v"(t0), "=&v"(t1) \
+      : "v"(le), "v"(lx), "v"(re[0]), "v"(re[1]), "v"(re[2]), "v"(re[3]), "v"(re[4]), "v"(re[5]), "v"(re[6]), \
+        "v"(re[7]), "v"(rx[0]), "v"(rx[1]), "v"(rx[2]), "v"(rx[3]), "v"(rx[4]), "v"(rx[5]), "v"(rx[6]), "v"(rx[7]))
+  if constexpr (I0 == 0) STM_SLIDE_BLOCK("0", "1", "2", "3", "4", "5", "6", "7");
+  else STM_SLIDE_BLOCK("8", "9", "10", "11", "12", "13", "14", "15");
+#undef STM_SLIDE_BLOCK
+#undef STM_SLIDE_TAP
+}
+#undef STM_SLIDE_UPD1
+
 // One row step of a strip: V += Q[entering row] - Q[leaving row].
 // EDGE: the strip touches the left clip (kc >= d) or the right image border.
 template <bool EDGE>
@@ -402,11 +465,36 @@ __device__ __forceinline__ void slide_step(float (&V)[kSlideNV], const SlideRow 
                                            const float *lds_x, int W, int c0, int d, int lane) {
   const int kc0 = c0 - kSlideK;
 #pragma unroll
-  for (int t = 0; t < kSlideNV; ++t) {
-    const float le = read_lane(t < 64 ? e.l0 : e.l1, t & 63);
-    const float lx = read_lane(t < 64 ? x.l0 : x.l1, t & 63);
-    const float de = le - lds_e[t + 63 - lane];
-    const float dx = lx - lds_x[t + 63 - lane];
+  for (int t0 = 0; t0 < kSlideNV; t0 += 8) {
+    float re[8], rx[8], de8[8], dx8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // (taps past the strip's last window column: any staged value, result unused)
+      const int t = t0 + i < kSlideNV ? t0 + i : kSlideNV - 1;
+      re[i] = lds_e[t + 63 - lane];
+      rx[i] = lds_x[t + 63 - lane];
+    }
+    if constexpr (!EDGE) {
+      float pad[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // (columns past the strip's last: unused)
+#define STM_V(i) (t0 + (i) < kSlideNV ? V[t0 + (i) < kSlideNV ? t0 + (i) : 0] : pad[i])
+      if ((t0 & 8) == 0)
+        slide_upd8<0>(STM_V(0), STM_V(1), STM_V(2), STM_V(3), STM_V(4), STM_V(5), STM_V(6), STM_V(7), e.l[t0 >> 4], x.l[t0 >> 4], re, rx);
+      else
+        slide_upd8<8>(STM_V(0), STM_V(1), STM_V(2), STM_V(3), STM_V(4), STM_V(5), STM_V(6), STM_V(7), e.l[t0 >> 4], x.l[t0 >> 4], re, rx);
+#undef STM_V
+      continue;
+    }
+    if ((t0 & 8) == 0) {
+      slide_sub8<0>(de8, e.l[t0 >> 4], re);
+      slide_sub8<0>(dx8, x.l[t0 >> 4], rx);
+    } else {
+      slide_sub8<8>(de8, e.l[t0 >> 4], re);
+      slide_sub8<8>(dx8, x.l[t0 >> 4], rx);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+    const int t = t0 + i;
+    if (t >= kSlideNV) break;
+    const float de = de8[i], dx = dx8[i];
     float qe = de * de;
     float qx = dx * dx;
     if (EDGE) {
@@ -423,6 +511,7 @@ __device__ __forceinline__ void slide_step(float (&V)[kSlideNV], const SlideRow 
       V[t] = d <= lim ? upd : V[t];
     } else {
       V[t] = (V[t] + qe) - qx;
+    }
     }
   }
 }
