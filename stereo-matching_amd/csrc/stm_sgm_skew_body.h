@@ -635,33 +635,31 @@ __device__ __forceinline__ void skew_wta(const float *St, int wave, int lane, co
                                          int32_t *__restrict__ disp, bool sp, int true_paths) {
   constexpr int LP = kWaves, NJ = kD / (LP * 4);  // lanes per pixel: a wave takes 64 / kWaves pixels
   typedef float v4f __attribute__((ext_vector_type(4)));
-  // Lane r of a pixel's LP lanes reads the 16-byte chunks M r + j % M + 16 (j / M), M = 16 / LP: the
-  // sixteen lanes of a quarter-wave (16 / LP pixels, a pixel's row 4 banks further than its
-  // predecessor's) then touch sixteen different bank groups (chunks r + LP j: up to four lanes on one).
-  constexpr int M = 16 / LP;
+  // (lane r of a pixel's LP lanes reads the 16-byte chunks r, r + LP, ...: with the sum tile's pixel
+  // stride of D + 16 floats the sixteen lanes of each ds_read_b128 lane group -- which are not
+  // contiguous, MI355X guide, LDS -- touch sixteen different 16-byte slots, as tile_wta_lds)
   const int pix = wave * (64 / LP) + lane / LP, r = lane % LP;
-  const float *p = St + pix * st_stride(kD) + r * (M * 4);
+  const float *p = St + pix * st_stride(kD) + r * 4;
   float best = __builtin_inff();
   int idxk = 0;
   bool nan0 = false;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const int cj = (j % M) + 16 * (j / M);  // the chunk, less the lane's M r
-    const v4f q = *reinterpret_cast<const v4f *>(p + cj * 4);
+    const v4f q = *reinterpret_cast<const v4f *>(p + j * LP * 4);
     const float v[4] = {q.x, q.y, q.z, q.w};
     if (j == 0) nan0 = r == 0 && v[0] != v[0];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const bool lt = v[e] < best;
       best = lt ? v[e] : best;
-      idxk = lt ? cj * 4 + e : idxk;
+      idxk = lt ? j * LP * 4 + e : idxk;
     }
   }
   float m = best;
   m = vmin_f32(m, dpp_f32<0xb1>(m, m));
   m = vmin_f32(m, dpp_f32<0x4e>(m, m));
   if (LP == 8) m = vmin_f32(m, dpp_f32<0x141>(m, m));  // row_half_mirror
-  int k = best == m ? idxk + r * (M * 4) : 0x7fffffff;
+  int k = best == m ? idxk + r * 4 : 0x7fffffff;
   k = nan0 ? 0 : k;
   int t;
   t = dpp_i32<0xb1>(k, k); k = t < k ? t : k;
