@@ -52,7 +52,12 @@ def main():
     trace = load(os.path.join(trace_dir, prefix + "_kernel_trace.csv"))
     agg = collections.defaultdict(list)
     for r in trace:
-        agg[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        k = short(r["Kernel_Name"])
+        # (the skewed-tile kernels of the two disparity counts carry the same name: four waves per
+        # workgroup at D = 128, eight at D = 256)
+        if k.startswith("sgm_skew_"):
+            k += " [D=%d]" % (128 if int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", "256"))) == 256 else 256)
+        agg[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     total = sum(sum(v) for v in agg.values())
     with open(os.path.join(HERE, tag + "_kernel_stats.csv"), "w") as f:
         f.write("kernel,calls,total_us,avg_us,min_us,max_us,percent\n")
@@ -65,7 +70,10 @@ def main():
         per = collections.defaultdict(list)
         for r in load(os.path.join(d, prefix + "_counter_collection.csv")):
             if r["Counter_Name"] == name:
-                per[(short(r["Kernel_Name"]), int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+                k = short(r["Kernel_Name"])
+                if k.startswith("sgm_skew_"):
+                    k += " [D=%d]" % (128 if int(r.get("Workgroup_Size", r.get("Workgroup_Size_X", "256"))) == 256 else 256)
+                per[(k, int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
         counters[name] = {k: sum(v) / len(v) for k, v in per.items()}
     keys = sorted(set(counters["FETCH_SIZE"]) | set(counters["WRITE_SIZE"]))
     with open(os.path.join(HERE, tag + "_hbm_counters.csv"), "w") as f:
