@@ -156,3 +156,39 @@ def test_register_soffset_buffer_stores_hold_their_data(tmp_path):
             assert held, "%s line %d: no s_nop behind %s" % (name, i + 1, l.strip())
         if name != "stm_dp.hip":
             assert n > 0, name + ": expected buffer stores with a register soffset"
+
+
+def test_tile_loops_touch_no_scratch_memory(tmp_path):
+    """ISA of the kernels that rebuild tiles (skewed-tile passes, tile kernels behind sweeps / walks):
+    no scratch or flat access beyond a kernel's prologue and epilogue.  A spilled register or an
+    array behind a pointer comes back by `scratch_load` + `s_waitcnt vmcnt(0)`, and vmcnt counts in
+    order: the wait covers the entry states and the next tile's cost rows requested ahead on
+    purpose -- a fifth of the skewed-tile forward pass until round 4."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    units = ("stm_sgm_skew_d128.hip", "stm_sgm_skew_d256.hip", "stm_sgm_tile.hip", "stm_sgm_tile_h2.hip")
+    procs = []
+    for name in units:
+        asm = str(tmp_path / (name + ".s"))
+        procs.append((name, asm, subprocess.Popen(
+            [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+             "-fhip-fp32-correctly-rounded-divide-sqrt", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+             "--cuda-device-only", "-S", os.path.join(CSRC, name), "-o", asm], stderr=subprocess.DEVNULL)))
+    for name, asm, p in procs:
+        assert p.wait() == 0, name
+        lines = open(asm).read().splitlines()
+        # the tile loop: the skewed-tile kernels' loop over a band's tiles lies inside the loop over the
+        # units (image, band) a workgroup takes; the tile kernels' loop over tiles is the outermost
+        tile_depth = 2 if "skew" in name else 1
+        kernel, depth, in_loop = None, 0, []
+        for l in lines:
+            m = re.match(r"^(_Z\w+):", l)
+            if m:
+                kernel, depth = m.group(1), 0
+            # (hipcc annotates every basic block of a loop: "; in Loop: Header=BB0_70 Depth=2")
+            if re.match(r"^\.LBB\d+_\d+:", l):
+                d = re.search(r"in Loop: Header=\S+ Depth=(\d+)", l)
+                depth = int(d.group(1)) if d else 0
+            if re.match(r"\s*(scratch_load|scratch_store|flat_load|flat_store)", l) and kernel and depth >= tile_depth:
+                in_loop.append((kernel, l.strip()))
+        assert not in_loop, "%s: scratch / flat accesses inside the tile loop:\n%s" % (
+            name, "\n".join("%s: %s" % kl for kl in in_loop[:10]))
