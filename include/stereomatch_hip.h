@@ -183,14 +183,15 @@ int stm_birchfield_ex_f32(const float *left, const float *right, float *cost,
  *                   picks by itself for single pairs and small batches at D >= 128;
  *                   STM_SGM_TILED means the sweep-fed variant wherever the device can hold it. */
 #define STM_SGM_WALKS 512
-/*   STM_SGM_SKEW    use the SKEWED-TILE form wherever it covers the call (D = 128, no ACCUMULATE /
+/*   STM_SGM_SKEW    use the SKEWED-TILE form wherever it covers the call (D = 128 or 256, no ACCUMULATE /
  *                   SINGLE_PASSES / EXACT_NONFINITE): two passes over sheared 8x8 tiles, each
  *                   reading the cost volume once and carrying its four directions from tile to
- *                   tile (stm_sgm_skew.hip): ~18 instead of 30 bytes per element.  Bands of tiles
+ *                   tile (stm_sgm_skew.hip): ~20 instead of 30 bytes per element.  Bands of tiles
  *                   wait for the band above / below through progress counters; units are taken by
  *                   ticket, so there is NO residency requirement; the waits are bounded all the
  *                   same and report through the status word like the sweeps'.  What the library
- *                   picks by itself for large D = 128 batches. */
+ *                   picks by itself from two (D = 128) / four (D = 256) bands of tiles per
+ *                   workgroup: 22 Teddy-sized pairs, eight 1080p pairs on an MI355X. */
 #define STM_SGM_SKEW 1024
 size_t stm_sgm_workspace_bytes(int H, int W, int D, int batch, int flags);
 /* 1 when stm_sgm_f32 / stm_sgm_wta_f32 select the tiled form for this shape on the current
