@@ -269,6 +269,28 @@ __device__ __forceinline__ float chain_penalties(const PK &KA, int naA, int nbA,
   const int u = pix & (kT - 1), r = pix >> 3;
   return sgm_penalty(Ip[(r + 1) * kIpW + u + 2], Ip[(r + dr + 1) * kIpW + u + du + 2], p1, p2);
 }
+// The same in two halves: where the lane's two samples lie in the intensity patch (byte offsets,
+// 16 bits each) is the same for every tile -- computed once per kernel; per tile two LDS reads and
+// the division are left (a third of the instructions).
+template <int PA, int SA, int PB, int SB>
+__device__ __forceinline__ unsigned chain_penalty_offsets(const PK &KA, int naA, int nbA, const PK &KB, int naB,
+                                                          int nbB, int lane) {
+  const int s = lane & 7;
+  const bool second = (lane >> 3) & 1;
+  const int na = second ? naB : naA, nb = second ? nbB : nbA;
+  const int q = s < na ? 0 : (s < nb ? 1 : 2);
+  const int start = q == 0 ? 0 : (q == 1 ? na : nb);
+  const int pixA = KA.pix[0] * (q == 0) + KA.pix[1] * (q == 1) + KA.pix[2] * (q == 2) + (s - start) * tile_pstep(PA);
+  const int pixB = KB.pix[0] * (q == 0) + KB.pix[1] * (q == 1) + KB.pix[2] * (q == 2) + (s - start) * tile_pstep(PB);
+  const int pix = second ? pixB : pixA;
+  const int du = second ? SB * tile_du(PB) : SA * tile_du(PA), dr = second ? SB * tile_dr(PB) : SA * tile_dr(PA);
+  const int u = pix & (kT - 1), r = pix >> 3;
+  return (unsigned)(((r + 1) * kIpW + u + 2) * 4) | ((unsigned)(((r + dr + 1) * kIpW + u + du + 2) * 4) << 16);
+}
+__device__ __forceinline__ float penalty_at(const float *Ip, unsigned o, float p1, float p2) {
+  const char *b = reinterpret_cast<const char *>(Ip);
+  return sgm_penalty(*reinterpret_cast<const float *>(b + (o & 0xffffu)), *reinterpret_cast<const float *>(b + (o >> 16)), p1, p2);
+}
 
 // Gen tiles: where the lane's chain BEGINS a path (L = C): bit s of `bf` / `bi`: slot s lies in the
 // image and its forward predecessor / successor does not.  Inside a piece the neighbour is the
@@ -783,11 +805,12 @@ __device__ __forceinline__ void fwd_tile(const SkewArgs &P, const TileCtx &T, co
   if (STM_SKEW_FWD_ENTRIES_AT == 0) { load_e2(); load_e3(); }
   float pen0, pen1, pen2, pen3;
   {
-    const PK K0 = kt_fetch<0>(Kt, L), K1 = kt_fetch<1>(Kt, L), K2 = kt_fetch<2>(Kt, L), K3 = kt_fetch<3>(Kt, L);
-    pen0 = chain_penalties<0, -1, 0, 1>(K0, kT, kT, K0, kT, kT, Ip, P.p1, P.p2, lane);
-    pen1 = chain_penalties<1, -1, 1, 1>(K1, na_of(1, w), kT, K1, na_of(1, w), kT, Ip, P.p1, P.p2, lane);
-    pen2 = chain_penalties<2, -1, 2, 1>(K2, na_of(2, w), nb_of(2, w), K2, na_of(2, w), nb_of(2, w), Ip, P.p1, P.p2, lane);
-    pen3 = chain_penalties<3, -1, 3, 1>(K3, kT, kT, K3, kT, kT, Ip, P.p1, P.p2, lane);
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const v4u o = *reinterpret_cast<const v4u *>(Kt + kKtWords + 4 * threadIdx.x);  // (fwd_penalty_table)
+    pen0 = penalty_at(Ip, o.x, P.p1, P.p2);
+    pen1 = penalty_at(Ip, o.y, P.p1, P.p2);
+    pen2 = penalty_at(Ip, o.z, P.p1, P.p2);
+    pen3 = penalty_at(Ip, o.w, P.p1, P.p2);
   }
   Row<4> Ef[3], Ei[3], Xf[3];
   // ---- pair 0: right / left
@@ -888,7 +911,7 @@ __global__ __launch_bounds__(kThreads, kD == 128 ? 2 : 1) void sgm_skew_fwd_kern
   __shared__ __attribute__((aligned(16))) float Ct[kT * kT * kD];
   __shared__ __attribute__((aligned(16))) float St[kT * kT * st_stride(kD)];
   __shared__ float Ip[kIpN];
-  __shared__ __attribute__((aligned(16))) unsigned Kt[kKtWords];
+  __shared__ __attribute__((aligned(16))) unsigned Kt[kKtWords + 4 * kThreads];
   __shared__ int s_unit;
   const SkewGeom &G = P.G;
   const int lane = threadIdx.x & 63;
@@ -897,6 +920,18 @@ __global__ __launch_bounds__(kThreads, kD == 128 ? 2 : 1) void sgm_skew_fwd_kern
   Ctx X;
   ctx_init(X, P.p1, L, P.dlim);
   kt_fill<0>(Kt, L); kt_fill<1>(Kt, L); kt_fill<2>(Kt, L); kt_fill<3>(Kt, L);  // (read behind the loop's first barrier)
+  {
+    // fwd_penalty_table: behind the chain table, four words per lane -- where the lane's samples of
+    // each pair's penalties lie in the intensity patch (chain_penalty_offsets).
+    PK K0, K1, K2, K3;
+    pk_init<0>(K0, L); pk_init<1>(K1, L); pk_init<2>(K2, L); pk_init<3>(K3, L);
+    const int w = L.w;
+    unsigned *po = Kt + kKtWords + 4 * threadIdx.x;
+    po[0] = chain_penalty_offsets<0, -1, 0, 1>(K0, kT, kT, K0, kT, kT, lane);
+    po[1] = chain_penalty_offsets<1, -1, 1, 1>(K1, na_of(1, w), kT, K1, na_of(1, w), kT, lane);
+    po[2] = chain_penalty_offsets<2, -1, 2, 1>(K2, na_of(2, w), nb_of(2, w), K2, na_of(2, w), nb_of(2, w), lane);
+    po[3] = chain_penalty_offsets<3, -1, 3, 1>(K3, kT, kT, K3, kT, kT, lane);
+  }
   unsigned *status = reinterpret_cast<unsigned *>(ws);
   unsigned *prog = reinterpret_cast<unsigned *>(ws + G.prog_off);
   const size_t npix = (size_t)G.H * G.W;
@@ -1000,12 +1035,13 @@ __device__ __forceinline__ void rev_bottoms(RevPre &N, const SkewGeom &G, const 
 __device__ __forceinline__ void rev_tile(const SkewArgs &P, const TileCtx &T, const TileCtx &Tn, const PK &K0,
                                          const PK &K1, const PK &K2, const PK &K3, RevCarry &C, RevPre &N,
                                          const float *image, const float *Ct, const float *Ip, Ctx &X,
-                                         const LaneId &L, int lane, unsigned *publish, unsigned published) {
+                                         const LaneId &L, int lane, unsigned *publish, unsigned published,
+                                         unsigned po01, unsigned po23) {
   const SkewGeom &G = P.G;
   const int w = L.w;
   const Row<4> b1 = N.b1, b2 = N.b2, b3 = N.b3;
-  const float pen01 = chain_penalties<0, 1, 1, 1>(K0, kT, kT, K1, na_of(1, w), kT, Ip, P.p1, P.p2, lane);
-  const float pen23 = chain_penalties<2, 1, 3, 1>(K2, na_of(2, w), nb_of(2, w), K3, kT, kT, Ip, P.p1, P.p2, lane);
+  const float pen01 = penalty_at(Ip, po01, P.p1, P.p2);
+  const float pen23 = penalty_at(Ip, po23, P.p1, P.p2);
   Row<4> Ea[3], Eb[3], Xa[3], Xb[3];
   // ---- pairs 0 (left) and 1 (up)
   Ea[0] = C.c0; Ea[1] = C.c0; Ea[2] = C.c0;
@@ -1094,6 +1130,9 @@ __global__ __launch_bounds__(kThreads, kD == 128 ? STM_SKEW_REV_OCC : 1) void sg
   ctx_init(X, P.p1, L, P.dlim);
   PK K0, K1, K2, K3;
   pk_init<0>(K0, L); pk_init<1>(K1, L); pk_init<2>(K2, L); pk_init<3>(K3, L);
+  // (where the lane's samples of the two penalty sets lie in the intensity patch: the same for every tile)
+  const unsigned po01 = chain_penalty_offsets<0, 1, 1, 1>(K0, kT, kT, K1, na_of(1, L.w), kT, lane);
+  const unsigned po23 = chain_penalty_offsets<2, 1, 3, 1>(K2, na_of(2, L.w), nb_of(2, L.w), K3, kT, kT, lane);
   unsigned *status = reinterpret_cast<unsigned *>(ws);
   unsigned *prog = reinterpret_cast<unsigned *>(ws + G.prog_off);
   const size_t npix = (size_t)G.H * G.W;
@@ -1140,7 +1179,7 @@ __global__ __launch_bounds__(kThreads, kD == 128 ? STM_SKEW_REV_OCC : 1) void sg
       lds_barrier();
       if (L.w == 0 && below) ahead = poll_counter(prog_below);
       unsigned *publish = jj > 0 ? prog_mine : nullptr;
-      rev_tile(P, T, Tn, K0, K1, K2, K3, C, N, image, Ct, Ip, X, L, lane, publish, (unsigned)jj);
+      rev_tile(P, T, Tn, K0, K1, K2, K3, C, N, image, Ct, Ip, X, L, lane, publish, (unsigned)jj, po01, po23);
       lds_barrier();  // (the next tile's staging overwrites the cost tile)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
