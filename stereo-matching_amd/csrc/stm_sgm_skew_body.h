@@ -23,6 +23,12 @@ using std::integral_constant;
 #ifndef STM_SKEW_FWD_SPREAD
 #define STM_SKEW_FWD_SPREAD 0
 #endif
+#ifndef STM_SKEW_COST_AUX
+#define STM_SKEW_COST_AUX 2  // cache policy of the cost rows' loads / the side blocks' stores (2: non-temporal)
+#endif
+#ifndef STM_SKEW_SIDE_AUX
+#define STM_SKEW_SIDE_AUX 2
+#endif
 #ifndef STM_SKEW_POLL_SLEEP
 #define STM_SKEW_POLL_SLEEP 16  // s_sleep between two polls of a progress counter (units of 64 clocks)
 #endif
@@ -208,13 +214,13 @@ __device__ __forceinline__ void prefetch_cost(Pre &P, const SkewGeom &G, const T
   if (!T.gen) {
     const unsigned base = ((unsigned)((T.y0 + r) * G.W + T.x0 - r) * (unsigned)kD + (unsigned)L.d0) * 4u;
 #pragma unroll
-    for (int u = 0; u < kT; ++u) P.cpre[u] = buf_load_row4<0>(T.cost, base + (unsigned)(u * kRowBytes), 0);
+    for (int u = 0; u < kT; ++u) P.cpre[u] = buf_load_row4<STM_SKEW_COST_AUX>(T.cost, base + (unsigned)(u * kRowBytes), 0);
   } else {
     const int y = imin_(T.y0 + r, G.H - 1);
 #pragma unroll
     for (int u = 0; u < kT; ++u) {
       const int x = imin_(imax_(T.x0 + u - r, 0), G.W - 1);
-      P.cpre[u] = buf_load_row4<0>(T.cost, ((unsigned)(y * G.W + x) * (unsigned)kD + (unsigned)L.d0) * 4u, 0);
+      P.cpre[u] = buf_load_row4<STM_SKEW_COST_AUX>(T.cost, ((unsigned)(y * G.W + x) * (unsigned)kD + (unsigned)L.d0) * 4u, 0);
     }
   }
   const int e = imin_((int)threadIdx.x, kIpN - 1);
@@ -236,7 +242,7 @@ __device__ __forceinline__ void prefetch_cost_row(Pre &P, const SkewGeom &G, con
     const int x = imin_(imax_(T.x0 + U - r, 0), G.W - 1);
     off = ((unsigned)(y * G.W + x) * (unsigned)kD + (unsigned)L.d0) * 4u;
   }
-  P.cpre[U] = buf_load_row4<0>(T.cost, off, 0);
+  P.cpre[U] = buf_load_row4<STM_SKEW_COST_AUX>(T.cost, off, 0);
 }
 __device__ __forceinline__ void prefetch_patch(Pre &P, const SkewGeom &G, const TileCtx &T, const float *image) {
   const int e = imin_((int)threadIdx.x, kIpN - 1);
@@ -1079,7 +1085,7 @@ __device__ __forceinline__ void rev_tile(const SkewArgs &P, const TileCtx &T, co
   lds_barrier();
   if (publish && threadIdx.x == 0) publish_progress(publish, published);
   C.c0 = Xa[0];
-  STM_X_STORE(buf_store_row4<0>(T.wsb, side_off(G, T, T.j, K0.rs[0]), 0, Xa[0]));
+  STM_X_STORE(buf_store_row4<STM_SKEW_SIDE_AUX>(T.wsb, side_off(G, T, T.j, K0.rs[0]), 0, Xa[0]));
   {
     // slot order [q0, q1]; the inverse chain leaves q1 at slot NA (Xb[1]) and q0 at slot 0 (Xb[0]).
     // first half-wave: q1 = B leaves to the left (carry + side), q0 = A leaves at the top;
@@ -1089,10 +1095,11 @@ __device__ __forceinline__ void rev_tile(const SkewArgs &P, const TileCtx &T, co
     const Row<4> top = sel_row(K1.carry_first && !main_diag, Xb[1], Xb[0]);
     C.c1 = left;
     const unsigned so = K1.carry_first ? K1.rs[0] : K1.rs[1];
-    STM_X_STORE(buf_store_row4<0>(T.wsb, side_off(G, T, T.j, so), 0, left));
+    STM_X_STORE(buf_store_row4<STM_SKEW_SIDE_AUX>(T.wsb, side_off(G, T, T.j, so), 0, left));
     STM_X_STORE(buf_store_row4<kXSc1>(T.wsb, rowb_off(G, T, 3, T.i, K1.rt, false), 0, top));
   }
-  // The next tile's cost rows and bottom entries (half a tile ahead; held in registers no longer).
+  // The next tile's cost rows and bottom entries (half a tile ahead; held in registers no longer -- a whole
+  // tile ahead measured the same).
   prefetch_cost(N.cost, G, Tn, image, L);
   rev_bottoms(N, G, Tn, K1, K2, K3);
   // ---- pairs 2 (up-left) and 3 (up-right)
@@ -1110,9 +1117,9 @@ __device__ __forceinline__ void rev_tile(const SkewArgs &P, const TileCtx &T, co
   // pair 2: P0 leaves at the top; P1 to the left (-> the next tile's P0), P2 to the left (-> its P1)
   STM_X_STORE(buf_store_row4<kXSc1>(T.wsb, rowb_off(G, T, 4, T.i, K2.rt, false), 0, Xa[0]));
   C.c2a = Xa[1];
-  STM_X_STORE(buf_store_row4<0>(T.wsb, side_off(G, T, T.j, K2.rs[1]), 0, Xa[1]));
+  STM_X_STORE(buf_store_row4<STM_SKEW_SIDE_AUX>(T.wsb, side_off(G, T, T.j, K2.rs[1]), 0, Xa[1]));
   C.c2b = sel_row(three, Xa[2], Xa[1]);
-  STM_X_STORE(buf_store_row4<0>(T.wsb, side_off(G, T, T.j, K2.rs[2]), 0, C.c2b));  // (wave 3: no third piece, offset kNowhere)
+  STM_X_STORE(buf_store_row4<STM_SKEW_SIDE_AUX>(T.wsb, side_off(G, T, T.j, K2.rs[2]), 0, C.c2b));  // (wave 3: no third piece, offset kNowhere)
   STM_X_STORE(buf_store_row4<kXSc1>(T.wsb, rowb_off(G, T, 5, T.i, K3.rt, false), 0, Xb[0]));
 }
 
