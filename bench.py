@@ -349,7 +349,7 @@ def latency_b1(device, reps=20):
     return out
 
 
-def config3_line(device, steps, batch=16):
+def config3_line(device, steps, batch=64):
     """BASELINE config 3: Teddy 450x375, Birchfield + SGM + dynamic-programming reduce, D=128
     (reported beside the primary workload; parity gate: the reference's DP digest)."""
     import stereomatch
