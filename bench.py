@@ -195,10 +195,15 @@ def timed_run(job, steps, warmup, world):
 
 
 def roofline(job, sgm_ms, traffic_and_note=(None, None)):
-    traffic, note = traffic_and_note
+    traffic, note = traffic_and_note[:2]
     algorithmic = 8.0 * job.n_elems * job.batch  # read cost once + write sum once
     achieved = algorithmic / (sgm_ms * 1e-3) / 1e9
     form = int(getattr(job.sgm, "_last_form", 0))  # 0 paired, 1 tiles behind row sweeps, 2 tiles behind walks
+    form_name = {0: "paired", 1: "tiled (sweeps)", 2: "tiled (walks)", 3: "skewed tiles"}[form]
+    if traffic is not None and len(traffic_and_note) > 2 and traffic_and_note[2] not in (None, form_name):
+        # (e.g. the shared-device rehearsal, which forces the paired form)
+        traffic, note = None, "profiles/traffic.json was measured on the form '%s', this run took '%s'" % (
+            traffic_and_note[2], form_name)
     tile = "sgm_tile_h2_kernel" if getattr(job, "D", 0) == 128 else "sgm_tile_kernel"
     kernels = {0: "paired form: sgm_ckpt_kernel + 4 x sgm_pair_kernel",
                1: "tiled form: sgm_hwalk_kernel + sgm_sweep_kernel (down, up) + " + tile,
@@ -206,7 +211,7 @@ def roofline(job, sgm_ms, traffic_and_note=(None, None)):
                3: "skewed-tile form: sgm_skew_rev_kernel + sgm_skew_fwd_kernel"}[form]
     return {"bound": "hbm", "traffic_note": note,
             "kernel": "semiglobal aggregation with fused WTA (stm_sgm_wta_f32), " + kernels,
-            "form": {0: "paired", 1: "tiled (sweeps)", 2: "tiled (walks)", 3: "skewed tiles"}[form],
+            "form": form_name,
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes": algorithmic, "ms": round(sgm_ms, 4),
@@ -249,7 +254,7 @@ def load_traffic(name, batch):
     have, want = doc.get("csrc_sha16"), csrc_sha16()
     if have != want:
         return None, "profiles/traffic.json was measured on kernel sources %s, this tree is %s" % (have, want)
-    return int(per_pair) * batch, None
+    return int(per_pair) * batch, None, doc.get(name + "_form")
 
 
 def cpu_baseline(budget_s=20.0):
